@@ -1,0 +1,71 @@
+"""ctypes binding of the C ABI in include/gpusort.h (libgpusort.so).
+
+There is deliberately NO fallback: if the HIP library has not been built, or
+does not export a declared symbol, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgpusort.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+GS_KEY_U32, GS_KEY_I32, GS_KEY_F32 = 0, 1, 2
+GS_GEN_UNIFORM, GS_GEN_ZIPF, GS_GEN_ENTROPY_AND, GS_GEN_ENUMERATED = 0, 1, 2, 3
+
+u64, i32, vp, sz = C.c_uint64, C.c_int, C.c_void_p, C.c_size_t
+pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); must list every symbol include/gpusort.h declares
+SIGNATURES = {
+    "gs_version": (i32, []),
+    "gs_error_string": (C.c_char_p, [i32]),
+    "gs_lsb_temp_bytes": (sz, [u64, i32]),
+    "gs_lsb_sort_u32": (i32, [vp, sz, pp, pp, C.POINTER(i32), u64, i32, i32, i32, i32, vp]),
+    "gs_lsb_geometry": (None, [u64, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "gs_lsb_upsweep_u32": (i32, [vp, vp, u64, i32, i32, i32, i32, vp]),
+    "gs_lsb_scan_spine": (i32, [vp, vp, u64, i32, vp]),
+    "gs_lsb_downsweep_u32": (i32, [vp, vp, vp, vp, vp, vp, u64, i32, i32, i32, i32, i32, vp]),
+    "gs_msb_temp_bytes": (sz, [u64, i32]),
+    "gs_msb_sort_u32": (i32, [vp, sz, vp, vp, u64, vp, vp, pp, pp, i32, vp, i32]),
+    "gs_shard_histogram_u32": (i32, [vp, u64, i32, vp, i32, vp]),
+    "gs_shard_partition_u32": (i32, [vp, sz, vp, vp, vp, vp, u64, i32, vp, i32, vp, i32, vp]),
+    "gs_generate_u32": (i32, [vp, u64, i32, u64, u64, i32, vp]),
+    "gs_check_sorted_u32": (i32, [vp, u64, i32, vp, vp]),
+    "gs_check_pairs_enumerated_u32": (i32, [vp, vp, vp, u64, vp, vp]),
+}
+
+
+class GpuSortError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__(f"{what}: hipError {code} ({error_string(code)})")
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or make -C gpu-sort_amd/csrc). "
+            "There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def error_string(code):
+    s = lib.gs_error_string(int(code))
+    return s.decode() if s else "?"
+
+
+def check(code, what):
+    if code != 0:
+        raise GpuSortError(code, what)

@@ -1,0 +1,146 @@
+// gs_util.hip -- version/error strings, on-device input generators and
+// size-independent result checks.  The generators restate oracle/oracle.c's
+// counter-based streams so CPU and GPU inputs are identical;
+// they stand in for the cuRAND fills of lsb/sort.cu:125-131,
+// msb/src/test.cu:38-43 and msb/tests/data_gen.h:33-84.
+#include "gs_device.hpp"
+#include "gs_host.hpp"
+
+namespace gs {
+
+constexpr uint64_t GOLDEN64 = 0x9E3779B97F4A7C15ull;
+
+__device__ __forceinline__ uint32_t uniform_at(uint64_t seed, uint64_t idx)
+{
+    return (uint32_t)(splitmix64(seed * GOLDEN64 + idx) >> 32);
+}
+
+__global__ __launch_bounds__(256) void generate_kernel(uint32_t *__restrict__ out, uint64_t n, int kind, uint64_t seed,
+                                                       uint64_t start, int level)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t idx = start + i;
+        uint32_t k;
+        if (kind == GS_GEN_UNIFORM) {
+            k = uniform_at(seed, idx);
+        } else if (kind == GS_GEN_ZIPF) {
+            const uint64_t h = splitmix64((seed + 0x2545F491ull) * GOLDEN64 + idx);
+            const uint32_t e = (uint32_t)(((h >> 32) * 24ull) >> 32);
+            const uint32_t m = (uint32_t)h & ((1u << e) - 1u);
+            k = ((1u << e) + m) * 0x9E3779B1u;
+        } else if (kind == GS_GEN_ENTROPY_AND) {
+            if (level < 1) {
+                k = 0;
+            } else {
+                k = uniform_at(seed, idx);
+                for (int l = 1; l < level; ++l) k &= uniform_at(seed + 17ull * (uint64_t)l, idx);
+            }
+        } else {
+            k = (uint32_t)idx;
+        }
+        out[i] = k;
+    }
+}
+
+// result[0] += adjacent inversions, [1] += sum splitmix64(key), [2] ^= same
+__global__ __launch_bounds__(256) void check_sorted_kernel(const uint32_t *__restrict__ keys, uint64_t n, int descending,
+                                                           unsigned long long *__restrict__ result)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long inv = 0, sum = 0, xr = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t a = keys[i];
+        if (i + 1 < n) {
+            const uint32_t b = keys[i + 1];
+            inv += descending ? (a < b) : (a > b);
+        }
+        const uint64_t h = splitmix64(a);
+        sum += h;
+        xr ^= h;
+    }
+    // wave reduce, one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) {
+        inv += __shfl_xor(inv, o, WAVE);
+        sum += __shfl_xor(sum, o, WAVE);
+        xr ^= __shfl_xor(xr, o, WAVE);
+    }
+    if (lane_id() == 0) {
+        if (inv) atomicAdd(&result[0], inv);
+        atomicAdd(&result[1], sum);
+        atomicXor(&result[2], xr);
+    }
+}
+
+__global__ __launch_bounds__(256) void check_pairs_enum_kernel(const uint32_t *__restrict__ keys_in,
+                                                               const uint32_t *__restrict__ keys_sorted,
+                                                               const uint32_t *__restrict__ vals, uint64_t n,
+                                                               unsigned long long *__restrict__ result)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0, sum = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t v = vals[i];
+        if (v >= n || keys_in[v] != keys_sorted[i]) ++bad;
+        sum += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        bad += __shfl_xor(bad, o, WAVE);
+        sum += __shfl_xor(sum, o, WAVE);
+    }
+    if (lane_id() == 0) {
+        if (bad) atomicAdd(&result[0], bad);
+        atomicAdd(&result[1], sum);
+    }
+}
+
+static inline uint32_t stream_grid(uint64_t n)
+{
+    const uint64_t b = (n + 255) / 256;
+    return (uint32_t)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" {
+
+int gs_version(void) { return GS_VERSION; }
+
+const char *gs_error_string(int err) { return hipGetErrorString((hipError_t)err); }
+
+int gs_generate_u32(uint32_t *d_out, uint64_t num_items, int kind, uint64_t seed, uint64_t start_index, int level,
+                    void *stream)
+{
+    if (kind < GS_GEN_UNIFORM || kind > GS_GEN_ENUMERATED) return hipErrorInvalidValue;
+    if (num_items == 0) return hipSuccess;
+    hipLaunchKernelGGL(generate_kernel, dim3(stream_grid(num_items)), dim3(256), 0, (hipStream_t)stream, d_out,
+                       num_items, kind, seed, start_index, level);
+    return (int)hipGetLastError();
+}
+
+int gs_check_sorted_u32(const uint32_t *d_keys, uint64_t num_items, int descending, uint64_t *d_result, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d_result, 0, 3 * sizeof(uint64_t), s);
+    if (e != hipSuccess) return (int)e;
+    if (num_items == 0) return hipSuccess;
+    hipLaunchKernelGGL(check_sorted_kernel, dim3(stream_grid(num_items)), dim3(256), 0, s, d_keys, num_items,
+                       descending, (unsigned long long *)d_result);
+    return (int)hipGetLastError();
+}
+
+int gs_check_pairs_enumerated_u32(const uint32_t *d_keys_in, const uint32_t *d_keys_sorted, const uint32_t *d_vals,
+                                  uint64_t num_items, uint64_t *d_result, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d_result, 0, 2 * sizeof(uint64_t), s);
+    if (e != hipSuccess) return (int)e;
+    if (num_items == 0) return hipSuccess;
+    hipLaunchKernelGGL(check_pairs_enum_kernel, dim3(stream_grid(num_items)), dim3(256), 0, s, d_keys_in,
+                       d_keys_sorted, d_vals, num_items, (unsigned long long *)d_result);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

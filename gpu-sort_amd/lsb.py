@@ -1,0 +1,157 @@
+"""LSB driver mirror: DoubleBuffer + DeviceRadixSort over the C ABI.
+
+Mirrors cub::DoubleBuffer (lsb/cub/cub/util_type.cuh:785-817) and the
+DoubleBuffer overloads of cub::DeviceRadixSort
+(lsb/cub/cub/device/device_radix_sort.cuh:248-272, 399-423, 595-621, 754-780),
+and the two timed wrappers of the reference driver (lsb/sort.cu:25-76).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+_KEY_TYPES = {torch.int32: _lib.GS_KEY_I32, torch.float32: _lib.GS_KEY_F32}
+if hasattr(torch, "uint32"):
+    _KEY_TYPES[torch.uint32] = _lib.GS_KEY_U32
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)
+
+
+def _check_buf(t, n, what):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f"{what}: expected a contiguous device tensor")
+    if t.element_size() != 4 or t.numel() < n:
+        raise ValueError(f"{what}: need >= {n} 4-byte elements")
+
+
+class DoubleBuffer:
+    """Pair of device buffers + selector (util_type.cuh:785-817)."""
+
+    def __init__(self, d_current=None, d_alternate=None):
+        self.d_buffers = [d_current, d_alternate]
+        self.selector = 0
+
+    def Current(self):
+        return self.d_buffers[self.selector]
+
+    def Alternate(self):
+        return self.d_buffers[self.selector ^ 1]
+
+
+class DeviceRadixSort:
+    """Two-phase API like CUB: call with d_temp_storage=None to get the size."""
+
+    @staticmethod
+    def _sort(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, begin_bit, end_bit, descending,
+              stream, key_type):
+        has_values = d_values is not None
+        need = lib.gs_lsb_temp_bytes(num_items, int(has_values))
+        if d_temp_storage is None:                      # dispatch_radix_sort.cuh:1110
+            return need
+        if end_bit is None:
+            end_bit = 32
+        if key_type is None:
+            key_type = _KEY_TYPES.get(d_keys.d_buffers[0].dtype, _lib.GS_KEY_U32)
+        for b in d_keys.d_buffers:
+            _check_buf(b, num_items, "d_keys")
+        keys = (C.c_void_p * 2)(d_keys.d_buffers[0].data_ptr(), d_keys.d_buffers[1].data_ptr())
+        vals = None
+        if has_values:
+            for b in d_values.d_buffers:
+                _check_buf(b, num_items, "d_values")
+            if d_values.selector != d_keys.selector:
+                raise ValueError("d_keys and d_values selectors differ")
+            vals = (C.c_void_p * 2)(d_values.d_buffers[0].data_ptr(), d_values.d_buffers[1].data_ptr())
+        sel = C.c_int(d_keys.selector)
+        err = lib.gs_lsb_sort_u32(C.c_void_p(d_temp_storage.data_ptr()), min(temp_storage_bytes, d_temp_storage.numel() * d_temp_storage.element_size()),
+                                  keys, vals, C.byref(sel), num_items, begin_bit, end_bit, int(descending),
+                                  key_type, _stream_ptr(stream))
+        check(err, "gs_lsb_sort_u32")
+        d_keys.selector = sel.value
+        if has_values:
+            d_values.selector = sel.value
+        return need
+
+    @staticmethod
+    def SortKeys(d_temp_storage, temp_storage_bytes, d_keys, num_items, begin_bit=0, end_bit=None, stream=None,
+                 key_type=None):
+        return DeviceRadixSort._sort(d_temp_storage, temp_storage_bytes, d_keys, None, num_items, begin_bit, end_bit,
+                                     False, stream, key_type)
+
+    @staticmethod
+    def SortKeysDescending(d_temp_storage, temp_storage_bytes, d_keys, num_items, begin_bit=0, end_bit=None,
+                           stream=None, key_type=None):
+        return DeviceRadixSort._sort(d_temp_storage, temp_storage_bytes, d_keys, None, num_items, begin_bit, end_bit,
+                                     True, stream, key_type)
+
+    @staticmethod
+    def SortPairs(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, begin_bit=0, end_bit=None,
+                  stream=None, key_type=None):
+        return DeviceRadixSort._sort(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, begin_bit,
+                                     end_bit, False, stream, key_type)
+
+    @staticmethod
+    def SortPairsDescending(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, begin_bit=0,
+                            end_bit=None, stream=None, key_type=None):
+        return DeviceRadixSort._sort(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, begin_bit,
+                                     end_bit, True, stream, key_type)
+
+
+def _timed(fn):
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop)
+
+
+def sortPairsGPU(d_key_buf, d_key_alt_buf, d_value_buf, d_value_alt_buf, num_items, key_type=None):
+    """lsb/sort.cu:25-47: ascending stable pair sort; returns (ms, d_keys, d_values)."""
+    d_keys, d_values = DoubleBuffer(d_key_buf, d_key_alt_buf), DoubleBuffer(d_value_buf, d_value_alt_buf)
+    nbytes = DeviceRadixSort.SortPairs(None, 0, d_keys, d_values, num_items)
+    temp = torch.empty(nbytes, dtype=torch.uint8, device=d_key_buf.device)
+    ms = _timed(lambda: DeviceRadixSort.SortPairs(temp, nbytes, d_keys, d_values, num_items, key_type=key_type))
+    return ms, d_keys, d_values
+
+
+def sortKeysGPU(d_key_buf, d_key_alt_buf, num_items, key_type=None):
+    """lsb/sort.cu:49-76: sizes with SortKeys, runs SortKeysDescending (:65); returns (ms, d_keys)."""
+    d_keys = DoubleBuffer(d_key_buf, d_key_alt_buf)
+    nbytes = DeviceRadixSort.SortKeys(None, 0, d_keys, num_items)
+    temp = torch.empty(nbytes, dtype=torch.uint8, device=d_key_buf.device)
+    ms = _timed(lambda: DeviceRadixSort.SortKeysDescending(temp, nbytes, d_keys, num_items, key_type=key_type))
+    return ms, d_keys
+
+
+def lsb_pass_kernels(keys_in, vals_in, shift, bits, descending=False, stream=None):
+    """Run the three kernels of ONE pass separately (bring-up / parity of SURVEY.md rows L4-L6).
+
+    Returns dict(spine_counts, spine_scanned, totals, keys_out, vals_out, grid, tile)."""
+    n = keys_in.numel()
+    g, t = C.c_uint32(), C.c_uint32()
+    lib.gs_lsb_geometry(n, int(vals_in is not None), C.byref(g), C.byref(t))
+    dev = keys_in.device
+    spine = torch.zeros(256 * g.value, dtype=torch.int32, device=dev)
+    totals = torch.zeros(256, dtype=torch.int32, device=dev)
+    keys_out = torch.empty_like(keys_in)
+    vals_out = torch.empty_like(vals_in) if vals_in is not None else None
+    sp = _stream_ptr(stream)
+    check(lib.gs_lsb_upsweep_u32(keys_in.data_ptr(), spine.data_ptr(), n, shift, bits, int(descending),
+                                 _lib.GS_KEY_U32, sp), "gs_lsb_upsweep_u32")
+    counts = spine.clone()
+    check(lib.gs_lsb_scan_spine(spine.data_ptr(), totals.data_ptr(), n, int(vals_in is not None), sp),
+          "gs_lsb_scan_spine")
+    check(lib.gs_lsb_downsweep_u32(keys_in.data_ptr(), keys_out.data_ptr(),
+                                   vals_in.data_ptr() if vals_in is not None else None,
+                                   vals_out.data_ptr() if vals_out is not None else None,
+                                   spine.data_ptr(), totals.data_ptr(), n, shift, bits, int(descending),
+                                   _lib.GS_KEY_U32, _lib.GS_KEY_U32, sp), "gs_lsb_downsweep_u32")
+    return dict(spine_counts=counts, spine_scanned=spine, totals=totals, keys_out=keys_out, vals_out=vals_out,
+                grid=g.value, tile=t.value)

@@ -1,0 +1,71 @@
+"""MSB driver mirror: rdxsrt_unstable_sort over the C ABI (gs_msb_sort_u32).
+
+Mirrors msb/src/sort/gpu_radix_sort.h: RDXSRT_SortedSequence (:31-34),
+rdxsrt_unstable_sort (:197-507, device pointers; the result lands in the
+caller's INPUT arrays for 32-bit keys, :359-360) and the host-pointer
+conveniences rdxsrt_unstable_sort_keys / _pairs (:511-587).
+"""
+import collections
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+from .lsb import _stream_ptr, _check_buf
+
+RDXSRT_SortedSequence = collections.namedtuple("RDXSRT_SortedSequence", ["sorted_keys", "sorted_values"])
+
+
+def rdxsrt_unstable_sort(dev_keys, dev_values, key_count, dev_sorted_keys_out, dev_sorted_values_out,
+                         pre_allocated_dm=None, stream=None, key_type=_lib.GS_KEY_U32, synchronize=True):
+    """Ascending, UNSTABLE sort.  dev_values/dev_sorted_values_out None = keys only
+    (msb/src/test.cu:53).  pre_allocated_dm: optional uint8 workspace tensor
+    (the reference's RDXSRT_GPUDataManager argument); allocated per call when None."""
+    _check_buf(dev_keys, key_count, "dev_keys")
+    _check_buf(dev_sorted_keys_out, key_count, "dev_sorted_keys_out")
+    has_values = dev_values is not None
+    if has_values:
+        _check_buf(dev_values, key_count, "dev_values")
+        _check_buf(dev_sorted_values_out, key_count, "dev_sorted_values_out")
+    need = lib.gs_msb_temp_bytes(key_count, int(has_values))
+    dm = pre_allocated_dm
+    if dm is None:
+        dm = torch.empty(max(need, 1), dtype=torch.uint8, device=dev_keys.device)
+    sk, sv = C.c_void_p(), C.c_void_p()
+    err = lib.gs_msb_sort_u32(dm.data_ptr(), dm.numel(), dev_keys.data_ptr(),
+                              dev_values.data_ptr() if has_values else None, key_count,
+                              dev_sorted_keys_out.data_ptr(),
+                              dev_sorted_values_out.data_ptr() if has_values else None,
+                              C.byref(sk), C.byref(sv), key_type, _stream_ptr(stream), int(synchronize))
+    check(err, "gs_msb_sort_u32")
+
+    def which(ptr, a, b):
+        if ptr is None or ptr == 0:
+            return None
+        return a if ptr == a.data_ptr() else b
+
+    return RDXSRT_SortedSequence(which(sk.value, dev_keys, dev_sorted_keys_out),
+                                 which(sv.value, dev_values, dev_sorted_values_out) if has_values else None)
+
+
+def rdxsrt_unstable_sort_keys(keys, key_count=None, device="cuda"):
+    """Host array in, sorted host array out (gpu_radix_sort.h:511-541)."""
+    keys = np.ascontiguousarray(keys)
+    n = keys.size if key_count is None else key_count
+    dev_keys = torch.from_numpy(keys.view(np.int32)[:n].copy()).to(device)
+    dev_keys_out = torch.empty_like(dev_keys)
+    seq = rdxsrt_unstable_sort(dev_keys, None, n, dev_keys_out, None)
+    return seq.sorted_keys.cpu().numpy().view(keys.dtype)
+
+
+def rdxsrt_unstable_sort_pairs(keys, values, key_count=None, device="cuda"):
+    """Host arrays in, sorted host arrays out (gpu_radix_sort.h:543-587)."""
+    keys, values = np.ascontiguousarray(keys), np.ascontiguousarray(values)
+    n = keys.size if key_count is None else key_count
+    dev_keys = torch.from_numpy(keys.view(np.int32)[:n].copy()).to(device)
+    dev_values = torch.from_numpy(values.view(np.int32)[:n].copy()).to(device)
+    dev_keys_out, dev_values_out = torch.empty_like(dev_keys), torch.empty_like(dev_values)
+    seq = rdxsrt_unstable_sort(dev_keys, dev_values, n, dev_keys_out, dev_values_out)
+    return seq.sorted_keys.cpu().numpy().view(keys.dtype), seq.sorted_values.cpu().numpy().view(values.dtype)

@@ -1,0 +1,149 @@
+/*
+ * gpusort.h -- C ABI of the MI355X-native radix sort (libgpusort.so).
+ *
+ * This is the drop-in boundary for the two sort drivers of
+ * anilshanbhag/gpu-sort.  The reference has no FFI of its own (both sorts are
+ * header templates instantiated in the caller's translation unit, SURVEY.md
+ * 8b); each entry point below names the reference call it replaces.  All
+ * citations are relative to the reference tree.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer owned by the caller;
+ *   - return value: 0 (= hipSuccess) or a hipError_t value; nothing throws;
+ *   - no global mutable state; entry points are re-entrant given distinct
+ *     streams and workspaces; `stream` is a hipStream_t passed as void*;
+ *   - LSB entry points only enqueue work on `stream` and return (like
+ *     cub::DeviceRadixSort, dispatch_radix_sort.cuh:899-979);
+ *   - counts are 64-bit in the signature; the current kernels index with
+ *     32-bit offsets, so num_items must be < 2^32 (the reference caps at
+ *     int / unsigned, device_radix_sort.cuh:599,606, gpu_radix_sort.h:526).
+ */
+#ifndef GPUSORT_H_
+#define GPUSORT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_VERSION 100
+
+/* Key categories: the order-preserving key -> u32 map applied on the first
+ * read and undone on the last write (cub::Traits<K>::TwiddleIn/Out,
+ * lsb/cub/cub/util_type.cuh:966-974, 1009-1017, 1079-1089). */
+enum gs_key_type {
+    GS_KEY_U32 = 0,   /* identity                                  */
+    GS_KEY_I32 = 1,   /* flip the sign bit                         */
+    GS_KEY_F32 = 2    /* negative: flip all bits; else flip sign   */
+};
+
+int         gs_version(void);
+const char *gs_error_string(int err);
+
+/* ------------------------------------------------------------------ LSB --
+ * Stable least-significant-digit radix sort, 8-bit digits, three kernels per
+ * pass (upsweep histogram -> spine scan -> downsweep scatter).
+ * Replaces cub::DeviceRadixSort::SortKeys / SortPairs / SortKeysDescending /
+ * SortPairsDescending, DoubleBuffer overloads
+ * (lsb/cub/cub/device/device_radix_sort.cuh:248-272, 595-621, 754-780),
+ * as called from lsb/sort.cu:36,42,59,65.                                   */
+
+/* Bytes of temp storage for a sort of num_items (spine + digit totals).
+ * Replaces the d_temp_storage==NULL size query
+ * (dispatch_radix_sort.cuh:1094-1110).  has_values is accepted for symmetry;
+ * like CUB with is_overwrite_okay the value path needs no extra scratch.    */
+size_t gs_lsb_temp_bytes(uint64_t num_items, int has_values);
+
+/* d_keys[2] / d_vals[2] are the two halves of a DoubleBuffer
+ * (util_type.cuh:785-817); *selector says which half is current on entry and
+ * which half holds the result on return.  d_vals == NULL sorts keys only.
+ * Both halves may be overwritten.  Sorts on key bits [begin_bit, end_bit).
+ * Errors: hipErrorInvalidValue for a NULL/too-small workspace, bad bit range
+ * or num_items >= 2^32 (util_device.cuh:90-93 behaviour).                    */
+int gs_lsb_sort_u32(void *d_temp, size_t temp_bytes,
+                    uint32_t *d_keys[2], uint32_t *d_vals[2], int *selector,
+                    uint64_t num_items, int begin_bit, int end_bit,
+                    int descending, int key_type, void *stream);
+
+/* Bring-up / test access to the three kernels of one pass (SURVEY.md 8a rows
+ * L4-L6): upsweep -> spine[digit*grid + block]; scan -> exclusive in place +
+ * totals; downsweep -> scatter.  `grid`/`tile` report the launch geometry
+ * the library uses for num_items so the oracle can mirror it.               */
+void gs_lsb_geometry(uint64_t num_items, int has_values, uint32_t *grid, uint32_t *tile);
+int  gs_lsb_upsweep_u32(const uint32_t *d_keys_in, uint32_t *d_spine, uint64_t num_items,
+                        int shift, int bits, int descending, int key_type_in, void *stream);
+int  gs_lsb_scan_spine(uint32_t *d_spine, uint32_t *d_totals, uint64_t num_items,
+                       int has_values, void *stream);
+int  gs_lsb_downsweep_u32(const uint32_t *d_keys_in, uint32_t *d_keys_out,
+                          const uint32_t *d_vals_in, uint32_t *d_vals_out,
+                          const uint32_t *d_spine, const uint32_t *d_totals,
+                          uint64_t num_items, int shift, int bits, int descending,
+                          int key_type_in, int key_type_out, void *stream);
+
+/* ------------------------------------------------------------------ MSB --
+ * Unstable most-significant-digit hybrid radix sort, ascending.
+ * Replaces rdxsrt_unstable_sort<K,V,IndexT>
+ * (msb/src/sort/gpu_radix_sort.h:197-507) as called from
+ * msb/src/test.cu:53,55 and gpu_radix_sort.h:529,570.                        */
+
+/* Workspace bytes (replaces RDXSRT_GPUDataManager sizing,
+ * gpu_radix_sort.h:50-166; one allocation instead of eight). */
+size_t gs_msb_temp_bytes(uint64_t num_items, int has_values);
+
+/* d_keys/d_vals: input arrays (d_vals NULL = keys only); d_keys_alt /
+ * d_vals_alt: scratch of the same size.  On return *d_sorted_keys /
+ * *d_sorted_vals point at the arrays holding the result -- for 32-bit keys
+ * these are the caller's INPUT arrays, as in the reference
+ * (gpu_radix_sort.h:359-360, 505-506).  Enqueues on `stream` and, when
+ * `synchronize` is nonzero, waits for completion like the reference does
+ * (gpu_radix_sort.h:489-491).                                                */
+int gs_msb_sort_u32(void *d_temp, size_t temp_bytes,
+                    uint32_t *d_keys, uint32_t *d_vals, uint64_t num_items,
+                    uint32_t *d_keys_alt, uint32_t *d_vals_alt,
+                    uint32_t **d_sorted_keys, uint32_t **d_sorted_vals,
+                    int key_type, void *stream, int synchronize);
+
+/* ------------------------------------------------ multi-GPU shard helpers --
+ * One process per GPU; the exchange itself (one all-to-all over RCCL/xGMI)
+ * is issued by the host between these calls (no reference
+ * counterpart -- the reference is single-GPU).                               */
+
+/* 2^bits-bin histogram (u64 counts) of the top `bits` bits of each key. */
+int gs_shard_histogram_u32(const uint32_t *d_keys, uint64_t num_items, int bits,
+                           uint64_t *d_hist, int key_type, void *stream);
+/* Stable partition by destination rank: d_dest_of_bin[top `bits` bits] gives
+ * the rank (monotone non-decreasing, < num_ranks <= 256).  Writes keys (and
+ * values) grouped by rank into d_*_out and the per-rank counts into
+ * d_counts[num_ranks] (u64).  d_temp as for gs_lsb_temp_bytes.               */
+int gs_shard_partition_u32(void *d_temp, size_t temp_bytes,
+                           const uint32_t *d_keys_in, uint32_t *d_keys_out,
+                           const uint32_t *d_vals_in, uint32_t *d_vals_out,
+                           uint64_t num_items, int bits, const uint8_t *d_dest_of_bin,
+                           int num_ranks, uint64_t *d_counts, int key_type, void *stream);
+
+/* -------------------------------------------------- on-device test inputs --
+ * Counter-based generators identical to oracle/oracle.c; they
+ * replace the cuRAND fills of lsb/sort.cu:125-131, msb/src/test.cu:38-43 and
+ * msb/tests/data_gen.h:33-84.                                                */
+enum gs_gen_kind { GS_GEN_UNIFORM = 0, GS_GEN_ZIPF = 1, GS_GEN_ENTROPY_AND = 2, GS_GEN_ENUMERATED = 3 };
+int gs_generate_u32(uint32_t *d_out, uint64_t num_items, int kind, uint64_t seed,
+                    uint64_t start_index, int level, void *stream);
+
+/* Size-independent result checks run on the device (used at full BASELINE
+ * sizes where a host oracle would take minutes): d_result[0] = number of
+ * adjacent inversions, [1] = sum of splitmix64(key), [2] = xor of the same. */
+int gs_check_sorted_u32(const uint32_t *d_keys, uint64_t num_items, int descending,
+                        uint64_t *d_result, void *stream);
+/* d_result[0] = number of i with d_keys_in[d_vals[i]] != d_keys_sorted[i] or
+ * d_vals[i] >= num_items, [1] = sum of d_vals (msb/tests/test_sort_pairs.cu
+ * :141-146,166-176 on the device).                                           */
+int gs_check_pairs_enumerated_u32(const uint32_t *d_keys_in, const uint32_t *d_keys_sorted,
+                                  const uint32_t *d_vals, uint64_t num_items,
+                                  uint64_t *d_result, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPUSORT_H_ */

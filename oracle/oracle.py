@@ -1,0 +1,212 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle.c, cpu_baseline.cpp).
+
+TEST INFRASTRUCTURE ONLY.  Importable only from tests/, from
+__graft_entry__.smoke() and from bench.py's cpu_baseline leg -- never from
+the product package (gpu-sort_amd/), which must fail loudly without its HIP
+library instead of falling back to anything here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_REF_PATH = os.path.join(_HERE, "_ref", "libref_mersenne.so")
+
+
+def build(force=False):
+    """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+        for f in ("oracle.c", "oracle.h", "cpu_baseline.cpp")
+    ):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF_PATH)):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+_lib = None
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        u64, i32, p = C.c_uint64, C.c_int, C.c_void_p
+        L.orc_splitmix64.restype = u64
+        L.orc_splitmix64.argtypes = [u64]
+        for name in ("orc_gen_uniform", "orc_gen_zipf"):
+            getattr(L, name).argtypes = [_u32p, u64, u64, u64]
+        L.orc_gen_entropy_and.argtypes = [_u32p, u64, u64, u64, i32]
+        L.orc_gen_enumerated.argtypes = [_u32p, u64, u64]
+        L.orc_mt_genrand_int32.restype = C.c_uint32
+        L.orc_mt_init_genrand.argtypes = [C.c_uint32]
+        L.orc_random_bits_u32.argtypes = [_u32p, u64, i32, i32, i32]
+        for name in ("orc_twiddle_in_u32", "orc_twiddle_in_i32", "orc_twiddle_in_f32", "orc_twiddle_out_f32"):
+            getattr(L, name).restype = C.c_uint32
+            getattr(L, name).argtypes = [C.c_uint32]
+        L.orc_lsb_reference_ranks.argtypes = [_u32p, u64, i32, i32, i32, _u32p]
+        L.orc_lsb_sort_keys.argtypes = [_u32p, _u32p, u64, i32, i32, i32]
+        L.orc_lsb_sort_pairs.argtypes = [_u32p, _u32p, _u32p, _u32p, u64, i32, i32, i32]
+        L.orc_even_share.argtypes = [u64, C.c_uint32, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
+        L.orc_upsweep.argtypes = [_u32p, u64, i32, i32, i32, C.c_uint32, C.c_uint32, _u32p]
+        L.orc_exclusive_scan.argtypes = [_u32p, u64]
+        L.orc_downsweep.argtypes = [_u32p, p, _u32p, p, u64, i32, i32, i32]
+        L.orc_lsd_radix_sort.argtypes = [_u32p, p, _u32p, p, u64, i32, i32, i32, C.POINTER(i32)]
+        L.orc_msb_check_keys.restype = u64
+        L.orc_msb_check_keys.argtypes = [_u32p, _u32p, u64]
+        L.orc_msb_check_pairs.restype = u64
+        L.orc_msb_check_pairs.argtypes = [_u32p, _u32p, _u32p, _u32p, u64]
+        L.orc_msb_check_pairs_enumerated.restype = u64
+        L.orc_msb_check_pairs_enumerated.argtypes = [_u32p, _u32p, _u32p, u64]
+        L.orc_multiset_checksum.argtypes = [_u32p, u64, C.POINTER(u64), C.POINTER(u64)]
+        L.orc_count_inversions_adjacent.restype = u64
+        L.orc_count_inversions_adjacent.argtypes = [_u32p, u64, i32]
+        L.orc_std_sort_u32.restype = C.c_double
+        L.orc_std_sort_u32.argtypes = [_u32p, u64]
+        L.orc_std_stable_sort_pairs.restype = C.c_double
+        L.orc_std_stable_sort_pairs.argtypes = [_u32p, _u32p, u64]
+        L.orc_std_sort_u32_mt.restype = C.c_double
+        L.orc_std_sort_u32_mt.argtypes = [_u32p, u64, i32, C.POINTER(i32)]
+        L.orc_hardware_threads.restype = i32
+        _lib = L
+    return _lib
+
+
+def ref_mersenne():
+    """The reference's own MT19937 (oracle/_ref), or None when not built."""
+    if not os.path.exists(_REF_PATH):
+        return None
+    R = C.CDLL(_REF_PATH)
+    R.ref_mt_genrand_int32.restype = C.c_uint32
+    R.ref_mt_init_by_array.argtypes = [C.POINTER(C.c_uint32), C.c_int]
+    R.ref_mt_init_genrand.argtypes = [C.c_uint32]
+    return R
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+# ---- generators ---------------------------------------------------------
+def gen_uniform(n, seed=0, start=0):
+    out = np.empty(n, np.uint32); lib().orc_gen_uniform(out, n, seed, start); return out
+
+
+def gen_zipf(n, seed=0, start=0):
+    out = np.empty(n, np.uint32); lib().orc_gen_zipf(out, n, seed, start); return out
+
+
+def gen_entropy_and(n, level, seed=0, start=0):
+    out = np.empty(n, np.uint32); lib().orc_gen_entropy_and(out, n, seed, start, level); return out
+
+
+def gen_enumerated(n, start=0):
+    out = np.empty(n, np.uint32); lib().orc_gen_enumerated(out, n, start); return out
+
+
+def cub_random_keys(n, entropy_reduction=0, begin_bit=0, end_bit=32, reseed=True):
+    """RANDOM keys exactly as lsb/cub/test/test_device_radix_sort.cu generates them."""
+    if reseed:
+        lib().orc_mt_init_cub_default()
+    out = np.empty(n, np.uint32)
+    lib().orc_random_bits_u32(out, n, entropy_reduction, begin_bit, end_bit)
+    return out
+
+
+# ---- LSB oracle -----------------------------------------------------------
+def lsb_sort_keys(keys, begin_bit=0, end_bit=32, descending=False):
+    keys = _c(keys); out = np.empty_like(keys)
+    lib().orc_lsb_sort_keys(keys, out, keys.size, begin_bit, end_bit, int(descending)); return out
+
+
+def lsb_sort_pairs(keys, vals, begin_bit=0, end_bit=32, descending=False):
+    keys, vals = _c(keys), _c(vals); ko, vo = np.empty_like(keys), np.empty_like(vals)
+    lib().orc_lsb_sort_pairs(keys, vals, ko, vo, keys.size, begin_bit, end_bit, int(descending))
+    return ko, vo
+
+
+def lsb_reference_ranks(keys, begin_bit=0, end_bit=32, descending=False):
+    keys = _c(keys); r = np.empty(keys.size, np.uint32)
+    lib().orc_lsb_reference_ranks(keys, keys.size, begin_bit, end_bit, int(descending), r); return r
+
+
+def even_share(num_tiles, grid, b):
+    lo, hi = C.c_uint64(), C.c_uint64()
+    lib().orc_even_share(num_tiles, grid, b, C.byref(lo), C.byref(hi)); return lo.value, hi.value
+
+
+def upsweep(keys, shift, bits, tile, grid, descending=False):
+    keys = _c(keys); spine = np.zeros((1 << bits) * grid, np.uint32)
+    lib().orc_upsweep(keys, keys.size, shift, bits, int(descending), tile, grid, spine); return spine
+
+
+def exclusive_scan(spine):
+    s = _c(spine).copy(); lib().orc_exclusive_scan(s, s.size); return s
+
+
+def downsweep(keys, vals, shift, bits, descending=False):
+    keys = _c(keys); ko = np.empty_like(keys)
+    if vals is None:
+        lib().orc_downsweep(keys, None, ko, None, keys.size, shift, bits, int(descending)); return ko, None
+    vals = _c(vals); vo = np.empty_like(vals)
+    lib().orc_downsweep(keys, vals.ctypes.data, ko, vo.ctypes.data, keys.size, shift, bits, int(descending))
+    return ko, vo
+
+
+def lsd_radix_sort(keys, vals=None, begin_bit=0, end_bit=32, descending=False):
+    k = _c(keys).copy(); kt = np.empty_like(k); sel = C.c_int(0)
+    if vals is None:
+        lib().orc_lsd_radix_sort(k, None, kt, None, k.size, begin_bit, end_bit, int(descending), C.byref(sel))
+        return (kt if sel.value else k), None
+    v = _c(vals).copy(); vt = np.empty_like(v)
+    lib().orc_lsd_radix_sort(k, v.ctypes.data, kt, vt.ctypes.data, k.size, begin_bit, end_bit,
+                             int(descending), C.byref(sel))
+    return (kt, vt) if sel.value else (k, v)
+
+
+# ---- MSB checkers ---------------------------------------------------------
+def msb_check_keys(keys_in, keys_sorted):
+    a, b = _c(keys_in), _c(keys_sorted)
+    return 0 if a.size != b.size and False else lib().orc_msb_check_keys(a, b, a.size)
+
+
+def msb_check_pairs(keys_in, vals_in, keys_sorted, vals_sorted):
+    return lib().orc_msb_check_pairs(_c(keys_in), _c(vals_in), _c(keys_sorted), _c(vals_sorted).copy(),
+                                     _c(keys_in).size)
+
+
+def msb_check_pairs_enumerated(keys_in, keys_sorted, vals_sorted):
+    return lib().orc_msb_check_pairs_enumerated(_c(keys_in), _c(keys_sorted), _c(vals_sorted), _c(keys_in).size)
+
+
+# ---- properties -----------------------------------------------------------
+def multiset_checksum(keys):
+    keys = _c(keys); s, x = C.c_uint64(), C.c_uint64()
+    lib().orc_multiset_checksum(keys, keys.size, C.byref(s), C.byref(x)); return s.value, x.value
+
+
+def count_inversions_adjacent(a, descending=False):
+    a = _c(a); return lib().orc_count_inversions_adjacent(a, a.size, int(descending))
+
+
+# ---- CPU baseline ---------------------------------------------------------
+def time_std_sort(keys):
+    k = _c(keys).copy(); return lib().orc_std_sort_u32(k, k.size), k
+
+
+def time_std_stable_sort_pairs(keys, vals):
+    k, v = _c(keys).copy(), _c(vals).copy(); return lib().orc_std_stable_sort_pairs(k, v, k.size), k, v
+
+
+def time_std_sort_mt(keys, threads=0):
+    k = _c(keys).copy(); used = C.c_int(0)
+    return lib().orc_std_sort_u32_mt(k, k.size, threads, C.byref(used)), used.value, k
+
+
+def hardware_threads():
+    return lib().orc_hardware_threads()

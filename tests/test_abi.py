@@ -1,0 +1,71 @@
+"""CPU tests: the C-ABI library loads here (no GPU) and exports every symbol
+include/gpusort.h declares; host-side sizing logic; no compute calls."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gpusort.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(gs):
+    from gpu_sort_amd import _lib
+    syms = _declared_symbols()
+    assert len(syms) >= 14
+    raw = C.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"libgpusort.so does not export {s}"
+        assert s in _lib.SIGNATURES, f"python binding lacks {s}"
+    assert set(_lib.SIGNATURES) == set(syms)
+
+
+def test_library_is_in_tree(gs):
+    assert os.path.realpath(gs.LIB_PATH).startswith(os.path.realpath(ROOT))
+    assert gs.lib.gs_version() == 100
+
+
+def test_temp_bytes_and_geometry(gs):
+    lib = gs.lib
+    g, t = C.c_uint32(), C.c_uint32()
+    lib.gs_lsb_geometry(1 << 30, 0, C.byref(g), C.byref(t))
+    assert t.value == 8192 and 256 <= g.value <= 4096
+    need = lib.gs_lsb_temp_bytes(1 << 30, 0)
+    assert need >= 256 * g.value * 4 + 1024 and need % 256 == 0
+    lib.gs_lsb_geometry(100, 0, C.byref(g), C.byref(t))
+    assert g.value == 1
+    assert lib.gs_lsb_temp_bytes(0, 0) > 0
+
+
+def test_argument_validation_without_gpu(gs):
+    # these return hipErrorInvalidValue (1) before touching the device
+    lib = gs.lib
+    sel = C.c_int(0)
+    keys = (C.c_void_p * 2)(16, 32)
+    assert lib.gs_lsb_sort_u32(None, 0, keys, None, C.byref(sel), 10, 0, 32, 0, 0, None) == 1   # no workspace
+    assert lib.gs_lsb_sort_u32(None, 0, keys, None, C.byref(sel), 10, 5, 4, 0, 0, None) == 1    # bad bits
+    assert lib.gs_lsb_sort_u32(None, 0, keys, None, C.byref(sel), 1 << 32, 0, 32, 0, 0, None) == 1
+    assert lib.gs_lsb_sort_u32(None, 0, keys, None, C.byref(sel), 0, 0, 32, 0, 0, None) == 0    # n == 0: no-op
+    assert lib.gs_lsb_sort_u32(None, 0, keys, None, C.byref(sel), 10, 7, 7, 0, 0, None) == 0    # 0 bits: no-op
+    assert sel.value == 0
+    assert b"invalid" in lib.gs_error_string(1).lower()
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    import importlib.util, sys
+    src = os.path.join(ROOT, "gpu-sort_amd", "_lib.py")
+    fake = tmp_path / "pkg"
+    fake.mkdir()
+    (fake / "_lib.py").write_text(open(src).read())
+    spec = importlib.util.spec_from_file_location("fake_lib", str(fake / "_lib.py"))
+    mod = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(mod)
+    except ImportError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("import must fail when libgpusort.so is absent")

@@ -1,0 +1,217 @@
+"""GPU parity tests for the LSB path, through the C ABI (libgpusort.so).
+
+Model: lsb/cub/test/test_device_radix_sort.cu -- key generators RANDOM (entropy
+reduction 0/3/6), UNIFORM(=2), INTEGER_SEED (:1052-1084); sizes n -> ceil(n/32)
+... 1, 0 (:1034-1046); bit ranges full / [1,31) / the two middle bits
+(:973-995); ascending + descending; keys-only and pairs; bit-exact compare
+(:790-804).  Expected results come from the CPU oracle (oracle/) and from the
+committed golden fixtures.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import to_dev, to_u32
+
+pytestmark = pytest.mark.gpu
+
+
+def _sort(gs, keys_np, vals_np=None, begin_bit=0, end_bit=32, descending=False, key_type=None, dev="cuda:0"):
+    n = keys_np.size
+    d_keys = gs.DoubleBuffer(to_dev(keys_np, dev), torch.empty(n, dtype=torch.int32, device=dev))
+    d_vals = None
+    if vals_np is not None:
+        d_vals = gs.DoubleBuffer(to_dev(vals_np, dev), torch.empty(n, dtype=torch.int32, device=dev))
+    kt = gs.GS_KEY_U32 if key_type is None else key_type
+    if d_vals is None:
+        fn = gs.DeviceRadixSort.SortKeysDescending if descending else gs.DeviceRadixSort.SortKeys
+        nbytes = fn(None, 0, d_keys, n)
+        temp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        fn(temp, nbytes, d_keys, n, begin_bit, end_bit, key_type=kt)
+        torch.cuda.synchronize()
+        return to_u32(d_keys.Current())[:n], None, d_keys
+    fn = gs.DeviceRadixSort.SortPairsDescending if descending else gs.DeviceRadixSort.SortPairs
+    nbytes = fn(None, 0, d_keys, d_vals, n)
+    temp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    fn(temp, nbytes, d_keys, d_vals, n, begin_bit, end_bit, key_type=kt)
+    torch.cuda.synchronize()
+    return to_u32(d_keys.Current())[:n], to_u32(d_vals.Current())[:n], d_keys
+
+
+def test_extension_loaded_is_in_tree(gs, cuda):
+    import os
+    maps = open("/proc/self/maps").read()
+    assert os.path.realpath(gs.LIB_PATH) in maps
+
+
+def test_golden_fixtures(gs, cuda, golden):
+    for tag in golden["cases"]:
+        tag = str(tag)
+        er, n, b, e, d = tag.split("_")
+        er, n, bb, eb, desc = int(er[2:]), int(n[1:]), int(b[1:]), int(e), int(d[1:])
+        keys = golden[f"keys_er{er}"][:n]
+        want = golden["v_" + tag]
+        ko, vo, _ = _sort(gs, keys, np.arange(n, dtype=np.uint32), bb, eb, bool(desc))
+        assert np.array_equal(vo, want), tag
+        assert np.array_equal(ko, keys[want]), tag
+        ko, _, _ = _sort(gs, keys, None, bb, eb, bool(desc))
+        if bb == 0 and eb == 32:
+            assert np.array_equal(ko, keys[want]), tag
+
+
+@pytest.mark.parametrize("shift,bits", [(0, 8), (8, 8), (24, 8), (29, 3)])
+@pytest.mark.parametrize("n", [1, 8191, 8192, 8193, 100003, 3 * 1024 * 8192 // 2 + 5])
+def test_three_kernels_of_one_pass(gs, cuda, oracle, n, shift, bits):
+    """upsweep counts, spine scan and downsweep scatter each match their oracle."""
+    keys = oracle.gen_uniform(n, seed=shift + 1)
+    vals = oracle.gen_enumerated(n)
+    r = gs.lsb_pass_kernels(to_dev(keys, cuda), to_dev(vals, cuda), shift, bits)
+    torch.cuda.synchronize()
+    counts = oracle.upsweep(keys, shift, bits, r["tile"], r["grid"])
+    got = to_u32(r["spine_counts"]).reshape(256, r["grid"])[: 1 << bits].reshape(-1)
+    assert np.array_equal(got, counts)
+    # device spine is always 256 rows; rows >= 2^bits are zero
+    assert to_u32(r["spine_counts"]).reshape(256, r["grid"])[1 << bits:].sum() == 0
+    # scan: row-exclusive + totals; flattened exclusive scan == oracle's
+    tot = to_u32(r["totals"])
+    rows = to_u32(r["spine_scanned"]).reshape(256, r["grid"])
+    flat = (rows + (np.cumsum(tot, dtype=np.uint64) - tot).astype(np.uint32)[:, None])[: 1 << bits].reshape(-1)
+    assert np.array_equal(flat, oracle.exclusive_scan(counts))
+    ko, vo = oracle.downsweep(keys, vals, shift, bits)
+    assert np.array_equal(to_u32(r["keys_out"]), ko)
+    assert np.array_equal(to_u32(r["vals_out"]), vo)
+
+
+def _cub_sizes(nmax):
+    out, n = [], nmax
+    while n > 1:
+        out.append(n)
+        n = (n + 31) // 32
+    return out + [1, 0]
+
+
+@pytest.mark.parametrize("entropy_reduction", [0, 3, 6])
+def test_cub_random_keys_size_sweep(gs, cuda, oracle, entropy_reduction):
+    nmax = 1000003
+    base = oracle.cub_random_keys(nmax, entropy_reduction)
+    for n in _cub_sizes(nmax):
+        keys = base[:n]
+        for desc in (False, True):
+            ko, _, _ = _sort(gs, keys, None, descending=desc)
+            assert np.array_equal(ko, oracle.lsb_sort_keys(keys, descending=desc)), (n, desc)
+        vals = oracle.gen_enumerated(n)
+        ko, vo, _ = _sort(gs, keys, vals)
+        ek, ev = oracle.lsb_sort_pairs(keys, vals)
+        assert np.array_equal(ko, ek) and np.array_equal(vo, ev), n
+
+
+@pytest.mark.parametrize("gen", ["uniform2", "integer_seed"])
+def test_cub_uniform_and_natural_keys(gs, cuda, oracle, gen):
+    n = 300007
+    keys = np.full(n, 2, np.uint32) if gen == "uniform2" else np.arange(n, dtype=np.uint32)
+    vals = oracle.gen_uniform(n, seed=5)
+    for desc in (False, True):
+        ko, vo, _ = _sort(gs, keys, vals, descending=desc)
+        ek, ev = oracle.lsb_sort_pairs(keys, vals, descending=desc)
+        assert np.array_equal(ko, ek) and np.array_equal(vo, ev)
+
+
+@pytest.mark.parametrize("begin_bit,end_bit", [(0, 32), (1, 31), (15, 17), (0, 8), (3, 12), (24, 32), (7, 7)])
+@pytest.mark.parametrize("desc", [False, True])
+def test_bit_ranges(gs, cuda, oracle, begin_bit, end_bit, desc):
+    n = 70001
+    keys = oracle.cub_random_keys(n, 0)
+    vals = oracle.gen_enumerated(n)
+    ko, vo, dk = _sort(gs, keys, vals, begin_bit, end_bit, desc)
+    ek, ev = oracle.lsb_sort_pairs(keys, vals, begin_bit, end_bit, desc)
+    assert np.array_equal(ko, ek) and np.array_equal(vo, ev)
+    # selector: one flip per 8-bit pass (dispatch_radix_sort.cuh:1158 rule)
+    assert dk.selector == (((end_bit - begin_bit) + 7) // 8) % 2
+
+
+def test_signed_and_float_keys(gs, cuda, oracle):
+    n = 200003
+    raw = oracle.gen_uniform(n, seed=11)
+    # int32
+    ko, _, _ = _sort(gs, raw, None, key_type=gs.GS_KEY_I32)
+    assert np.array_equal(ko.view(np.int32), np.sort(raw.view(np.int32)))
+    ko, _, _ = _sort(gs, raw, None, descending=True, key_type=gs.GS_KEY_I32)
+    assert np.array_equal(ko.view(np.int32), np.sort(raw.view(np.int32))[::-1])
+    # float32 (the LSB driver's real key type, lsb/sort.cu:111,130): no NaNs, as RandomBits guarantees
+    f = raw.view(np.float32).copy()
+    f[np.isnan(f)] = 1.0
+    f[:5] = [-0.0, 0.0, -np.inf, np.inf, -1.5]
+    ko, _, _ = _sort(gs, f.view(np.uint32), None, key_type=gs.GS_KEY_F32)
+    tw = np.array(f.view(np.uint32))
+    order = np.argsort(np.where(tw >> 31 == 1, ~tw, tw | 0x80000000), kind="stable")
+    assert np.array_equal(ko, f.view(np.uint32)[order])
+    vals = oracle.gen_enumerated(n)
+    ko, vo, _ = _sort(gs, f.view(np.uint32), vals, descending=True, key_type=gs.GS_KEY_F32)
+    order = np.argsort(~np.where(tw >> 31 == 1, ~tw, tw | 0x80000000), kind="stable")
+    assert np.array_equal(vo, vals[order])
+
+
+def test_driver_wrappers_like_lsb_sort_cu(gs, cuda, oracle):
+    """sortPairsGPU ascending; sortKeysGPU sorts DESCENDING (lsb/sort.cu:65)."""
+    n = 1 << 20
+    keys = oracle.gen_uniform(n)
+    vals = oracle.gen_uniform(n, seed=1)
+    kb, ka = to_dev(keys, cuda), torch.empty(n, dtype=torch.int32, device=cuda)
+    vb, va = to_dev(vals, cuda), torch.empty(n, dtype=torch.int32, device=cuda)
+    ms, dk, dv = gs.sortPairsGPU(kb, ka, vb, va, n, key_type=gs.GS_KEY_U32)
+    ek, ev = oracle.lsb_sort_pairs(keys, vals)
+    assert ms > 0 and np.array_equal(to_u32(dk.Current()), ek) and np.array_equal(to_u32(dv.Current()), ev)
+    kb.copy_(to_dev(keys, cuda))
+    ms, dk = gs.sortKeysGPU(kb, ka, n, key_type=gs.GS_KEY_U32)
+    assert np.array_equal(to_u32(dk.Current()), np.sort(keys)[::-1])
+
+
+def test_workspace_too_small_is_an_error(gs, cuda):
+    n = 10000
+    d_keys = gs.DoubleBuffer(torch.zeros(n, dtype=torch.int32, device=cuda), torch.zeros(n, dtype=torch.int32, device=cuda))
+    temp = torch.empty(16, dtype=torch.uint8, device=cuda)
+    with pytest.raises(gs.GpuSortError):
+        gs.DeviceRadixSort.SortKeys(temp, 16, d_keys, n)
+
+
+def test_unaligned_input_pointer(gs, cuda, oracle):
+    n = 50001
+    keys = oracle.gen_uniform(n + 3, seed=4)
+    buf = to_dev(keys, cuda)
+    alt = torch.empty(n + 3, dtype=torch.int32, device=cuda)
+    d_keys = gs.DoubleBuffer(buf[3:], alt[1:n + 1])
+    nb = gs.DeviceRadixSort.SortKeys(None, 0, d_keys, n)
+    temp = torch.empty(nb, dtype=torch.uint8, device=cuda)
+    gs.DeviceRadixSort.SortKeys(temp, nb, d_keys, n, key_type=gs.GS_KEY_U32)
+    torch.cuda.synchronize()
+    assert np.array_equal(to_u32(d_keys.Current())[:n], np.sort(keys[3:]))
+
+
+@pytest.mark.parametrize("with_values", [False, True])
+def test_large_properties(gs, cuda, with_values):
+    """2^27 keys: device-side sortedness + multiset checksum + enumerated-value check
+    (size-independent properties; the full 2^30 case runs in bench.py --verify)."""
+    n = 1 << 27
+    keys = gs.generate_uniform_keys(n, seed=0, device=cuda)
+    _, s0, x0 = gs.check_sorted(keys)
+    orig = keys.clone()
+    d_keys = gs.DoubleBuffer(keys, torch.empty_like(keys))
+    if with_values:
+        d_vals = gs.DoubleBuffer(gs.generate_enumerated_values(n, device=cuda), torch.empty_like(keys))
+        nb = gs.DeviceRadixSort.SortPairs(None, 0, d_keys, d_vals, n)
+        temp = torch.empty(nb, dtype=torch.uint8, device=cuda)
+        gs.DeviceRadixSort.SortPairs(temp, nb, d_keys, d_vals, n, key_type=gs.GS_KEY_U32)
+    else:
+        nb = gs.DeviceRadixSort.SortKeys(None, 0, d_keys, n)
+        temp = torch.empty(nb, dtype=torch.uint8, device=cuda)
+        gs.DeviceRadixSort.SortKeys(temp, nb, d_keys, n, key_type=gs.GS_KEY_U32)
+    inv, s1, x1 = gs.check_sorted(d_keys.Current())
+    assert inv == 0 and (s1, x1) == (s0, x0)
+    if with_values:
+        bad, vsum = gs.check_pairs_enumerated(orig, d_keys.Current(), d_vals.Current())
+        assert bad == 0 and vsum == n * (n - 1) // 2
+        # stability: inside equal-key runs the enumerated values must ascend
+        k = d_keys.Current()[: 1 << 22].cpu().numpy().view(np.uint32)
+        v = d_vals.Current()[: 1 << 22].cpu().numpy().view(np.uint32)
+        same = k[1:] == k[:-1]
+        assert np.all(v[1:][same] > v[:-1][same])

@@ -1,0 +1,176 @@
+"""CPU tests: the oracle against the reference's MT19937, the committed golden
+fixtures and independent numpy sorts (the parity pin, DESIGN.md "Oracle")."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+
+def test_mt19937_known_answer(oracle):
+    # canonical MT19937 init_by_array{0x123,0x234,0x345,0x456} stream
+    oracle.lib().orc_mt_init_cub_default()
+    got = [oracle.lib().orc_mt_genrand_int32() for _ in range(4)]
+    assert got == [1067595299, 955945823, 477289528, 4107218783]
+
+
+def test_mt19937_matches_reference_build(oracle):
+    R = oracle.ref_mersenne()
+    if R is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    init = (C.c_uint32 * 4)(0x123, 0x234, 0x345, 0x456)
+    R.ref_mt_init_by_array(init, 4)
+    oracle.lib().orc_mt_init_cub_default()
+    for _ in range(5000):
+        assert R.ref_mt_genrand_int32() == oracle.lib().orc_mt_genrand_int32()
+    R.ref_mt_init_genrand(12345)
+    oracle.lib().orc_mt_init_genrand(12345)
+    for _ in range(2000):
+        assert R.ref_mt_genrand_int32() == oracle.lib().orc_mt_genrand_int32()
+
+
+def test_random_bits_matches_golden_inputs(oracle, golden):
+    # golden inputs were produced from the reference-built MT19937 + numpy AND
+    for er in (0, 3):
+        want = golden[f"keys_er{er}"]
+        got = oracle.cub_random_keys(want.size, entropy_reduction=er)
+        assert np.array_equal(got, want)
+    assert list(golden["mt_first8"][:4]) == [1067595299, 955945823, 477289528, 4107218783]
+
+
+def test_random_bits_bit_range(oracle):
+    k = oracle.cub_random_keys(1000, 0, 4, 20)
+    assert (k & ~np.uint32(((1 << 16) - 1) << 4)).max() == 0
+    assert oracle.cub_random_keys(10, -1).max() == 0
+
+
+def _parse(tag):
+    er, n, b, e, d = tag.split("_")
+    return int(er[2:]), int(n[1:]), int(b[1:]), int(e), int(d[1:])
+
+
+def test_oracle_matches_golden(oracle, golden):
+    for tag in golden["cases"]:
+        er, n, bb, eb, desc = _parse(str(tag))
+        keys = golden[f"keys_er{er}"][:n]
+        want = golden["v_" + str(tag)]
+        ranks = oracle.lsb_reference_ranks(keys, bb, eb, bool(desc))
+        assert np.array_equal(ranks, want), tag
+        ko, vo = oracle.lsb_sort_pairs(keys, np.arange(n, dtype=np.uint32), bb, eb, bool(desc))
+        assert np.array_equal(vo, want) and np.array_equal(ko, keys[want]), tag
+        # the 8-bit LSD restatement (north_star formulation) gives the same answer
+        k2, v2 = oracle.lsd_radix_sort(keys, np.arange(n, dtype=np.uint32), bb, eb, bool(desc))
+        assert np.array_equal(v2, want) and np.array_equal(k2, keys[want]), tag
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 1000, 8192, 100003])
+def test_oracle_vs_numpy(oracle, n):
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    if n > 10:
+        keys[: n // 3] &= 0xFF  # plenty of duplicates
+    vals = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    assert np.array_equal(oracle.lsb_sort_keys(keys), np.sort(keys))
+    order = np.argsort(keys, kind="stable")
+    ko, vo = oracle.lsb_sort_pairs(keys, vals)
+    assert np.array_equal(ko, keys[order]) and np.array_equal(vo, vals[order])
+    order = np.argsort(~keys, kind="stable")
+    ko, vo = oracle.lsb_sort_pairs(keys, vals, descending=True)
+    assert np.array_equal(ko, keys[order]) and np.array_equal(vo, vals[order])
+
+
+def test_per_kernel_goldens_compose(oracle):
+    # upsweep -> scan -> (block, digit) bases reproduce the stable pass
+    n, tile, grid = 50000, 8192, 4
+    keys = oracle.gen_uniform(n, seed=3)
+    counts = oracle.upsweep(keys, 8, 8, tile, grid)
+    assert counts.sum() == n
+    assert np.array_equal(counts.reshape(256, grid).sum(1), np.bincount((keys >> 8) & 0xFF, minlength=256))
+    scanned = oracle.exclusive_scan(counts)
+    assert scanned[0] == 0 and scanned[-1] + counts[-1] == n
+    ko, _ = oracle.downsweep(keys, None, 8, 8)
+    assert np.array_equal(ko, keys[np.argsort((keys >> 8) & 0xFF, kind="stable")])
+    # block b's first key of digit d lands at scanned[d*grid+b]
+    nt = (n + tile - 1) // tile
+    for b in range(grid):
+        lo, hi = oracle.even_share(nt, grid, b)
+        seg = keys[lo * tile: min(hi * tile, n)]
+        for d in (0, 17, 255):
+            idx = np.nonzero(((seg >> 8) & 0xFF) == d)[0]
+            if idx.size:
+                assert ko[scanned[d * grid + b]] == seg[idx[0]]
+
+
+def test_generators(oracle):
+    u = oracle.gen_uniform(1 << 16)
+    assert np.array_equal(u[100:200], oracle.gen_uniform(100, start=100))  # counter-based
+    assert abs(np.unpackbits(u.view(np.uint8)).mean() - 0.5) < 0.01
+    z = oracle.gen_zipf(1 << 16)
+    assert np.unique(z).size < z.size * 0.7  # heavy duplicates
+    assert oracle.gen_entropy_and(100, 0).max() == 0
+    e3 = oracle.gen_entropy_and(1 << 16, 3)
+    assert abs(np.unpackbits(e3.view(np.uint8)).mean() - 0.125) < 0.01
+    e1 = oracle.gen_entropy_and(1 << 10, 1)
+    assert np.array_equal(e1, oracle.gen_uniform(1 << 10))
+    assert np.array_equal(oracle.gen_enumerated(5, 3), np.arange(3, 8, dtype=np.uint32))
+
+
+def test_twiddles(oracle):
+    f = np.array([-np.inf, -1.5, -0.0, 0.0, 1e-30, 2.5, np.inf], dtype=np.float32)
+    tw = np.array([oracle.lib().orc_twiddle_in_f32(int(x)) for x in f.view(np.uint32)], dtype=np.uint32)
+    assert np.all(np.diff(tw.astype(np.int64)) > 0)
+    back = np.array([oracle.lib().orc_twiddle_out_f32(int(x)) for x in tw], dtype=np.uint32)
+    assert np.array_equal(back, f.view(np.uint32))
+    i = np.array([-2**31, -5, 0, 7, 2**31 - 1], dtype=np.int32)
+    tw = np.array([oracle.lib().orc_twiddle_in_i32(int(x)) for x in i.view(np.uint32)], dtype=np.uint32)
+    assert np.all(np.diff(tw.astype(np.int64)) > 0)
+
+
+def test_msb_checkers(oracle):
+    n = 5000
+    keys = oracle.gen_entropy_and(n, 4, seed=1)      # many duplicate keys
+    vals = oracle.gen_enumerated(n)
+    order = np.argsort(keys, kind="stable")
+    ks, vs = keys[order], vals[order]
+    assert oracle.msb_check_keys(keys, ks) == 0
+    assert oracle.msb_check_pairs_enumerated(keys, ks, vs) == 0
+    assert oracle.msb_check_pairs(keys, vals, ks, vs) == 0
+    # an unstable but valid result: reverse values inside every equal-key run
+    vs2 = vs.copy()
+    start = 0
+    for i in range(1, n + 1):
+        if i == n or ks[i] != ks[start]:
+            vs2[start:i] = vs2[start:i][::-1]
+            start = i
+    assert not np.array_equal(vs, vs2)
+    assert oracle.msb_check_pairs(keys, vals, ks, vs2) == 0
+    assert oracle.msb_check_pairs_enumerated(keys, ks, vs2) == 0
+    # broken results are caught
+    bad = ks.copy(); bad[[10, 11]] = bad[[11, 10]] if bad[10] != bad[11] else (bad[10] + 1, bad[11])
+    assert oracle.msb_check_keys(keys, bad) != 0
+    vbad = vs.copy(); vbad[0] = vbad[-1]
+    assert oracle.msb_check_pairs_enumerated(keys, ks, vbad) != 0
+    assert oracle.msb_check_pairs(keys, vals, ks, vbad) != 0
+
+
+def test_properties(oracle):
+    k = oracle.gen_uniform(10000, seed=9)
+    s = np.sort(k)
+    assert oracle.multiset_checksum(k) == oracle.multiset_checksum(s)
+    assert oracle.count_inversions_adjacent(s) == 0
+    assert oracle.count_inversions_adjacent(s[::-1].copy(), descending=True) == 0
+    assert oracle.count_inversions_adjacent(k) > 0
+    k2 = k.copy(); k2[5] ^= 1
+    assert oracle.multiset_checksum(k2) != oracle.multiset_checksum(k)
+
+
+def test_cpu_baseline_sorts(oracle):
+    k = oracle.gen_uniform(1 << 16, seed=2)
+    dt, s = oracle.time_std_sort(k)
+    assert dt > 0 and np.array_equal(s, np.sort(k))
+    dt, used, s = oracle.time_std_sort_mt(k, 4)
+    assert used == 4 and np.array_equal(s, np.sort(k))
+    v = oracle.gen_enumerated(k.size)
+    dt, ks, vs = oracle.time_std_stable_sort_pairs(k & 0xFF, v)
+    order = np.argsort(k & 0xFF, kind="stable")
+    assert np.array_equal(vs, v[order])
