@@ -15,27 +15,27 @@ __device__ __forceinline__ uint32_t uniform_at(uint64_t seed, uint64_t idx)
     return (uint32_t)(splitmix64(seed * GOLDEN64 + idx) >> 32);
 }
 
-__global__ __launch_bounds__(256) void generate_kernel(uint32_t *__restrict__ out, uint64_t n, int kind, uint64_t seed,
+// One instantiation per generator kind (wave-uniform `kind` branches inside a
+// single kernel were mis-structurized by hipcc 7.2: the enumerated branch
+// stored an undefined register).
+template <int KIND>
+__global__ __launch_bounds__(256) void generate_kernel(uint32_t *__restrict__ out, uint64_t n, uint64_t seed,
                                                        uint64_t start, int level)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t idx = start + i;
         uint32_t k;
-        if (kind == GS_GEN_UNIFORM) {
+        if (KIND == GS_GEN_UNIFORM) {
             k = uniform_at(seed, idx);
-        } else if (kind == GS_GEN_ZIPF) {
+        } else if (KIND == GS_GEN_ZIPF) {
             const uint64_t h = splitmix64((seed + 0x2545F491ull) * GOLDEN64 + idx);
             const uint32_t e = (uint32_t)(((h >> 32) * 24ull) >> 32);
             const uint32_t m = (uint32_t)h & ((1u << e) - 1u);
             k = ((1u << e) + m) * 0x9E3779B1u;
-        } else if (kind == GS_GEN_ENTROPY_AND) {
-            if (level < 1) {
-                k = 0;
-            } else {
-                k = uniform_at(seed, idx);
-                for (int l = 1; l < level; ++l) k &= uniform_at(seed + 17ull * (uint64_t)l, idx);
-            }
+        } else if (KIND == GS_GEN_ENTROPY_AND) {
+            k = (level < 1) ? 0u : uniform_at(seed, idx);
+            for (int l = 1; l < level; ++l) k &= uniform_at(seed + 17ull * (uint64_t)l, idx);
         } else {
             k = (uint32_t)idx;
         }
@@ -115,8 +115,14 @@ int gs_generate_u32(uint32_t *d_out, uint64_t num_items, int kind, uint64_t seed
 {
     if (kind < GS_GEN_UNIFORM || kind > GS_GEN_ENUMERATED) return hipErrorInvalidValue;
     if (num_items == 0) return hipSuccess;
-    hipLaunchKernelGGL(generate_kernel, dim3(stream_grid(num_items)), dim3(256), 0, (hipStream_t)stream, d_out,
-                       num_items, kind, seed, start_index, level);
+    const dim3 g(stream_grid(num_items)), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (kind) {
+    case GS_GEN_UNIFORM: hipLaunchKernelGGL(generate_kernel<GS_GEN_UNIFORM>, g, b, 0, s, d_out, num_items, seed, start_index, level); break;
+    case GS_GEN_ZIPF: hipLaunchKernelGGL(generate_kernel<GS_GEN_ZIPF>, g, b, 0, s, d_out, num_items, seed, start_index, level); break;
+    case GS_GEN_ENTROPY_AND: hipLaunchKernelGGL(generate_kernel<GS_GEN_ENTROPY_AND>, g, b, 0, s, d_out, num_items, seed, start_index, level); break;
+    default: hipLaunchKernelGGL(generate_kernel<GS_GEN_ENUMERATED>, g, b, 0, s, d_out, num_items, seed, start_index, level); break;
+    }
     return (int)hipGetLastError();
 }
 

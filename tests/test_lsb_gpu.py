@@ -215,3 +215,20 @@ def test_large_properties(gs, cuda, with_values):
         v = d_vals.Current()[: 1 << 22].cpu().numpy().view(np.uint32)
         same = k[1:] == k[:-1]
         assert np.all(v[1:][same] > v[:-1][same])
+
+
+def test_device_generators_match_oracle(gs, cuda, oracle):
+    n = 100000
+    cases = [
+        (gs.generate_uniform_keys(n, seed=3, start=5, device=cuda), oracle.gen_uniform(n, 3, 5)),
+        (gs.generate_zipf_keys(n, seed=3, start=5, device=cuda), oracle.gen_zipf(n, 3, 5)),
+        (gs.generate_random_keys(n, seed=3, entropy_level=3, start=5, device=cuda), oracle.gen_entropy_and(n, 3, 3, 5)),
+        (gs.generate_random_keys(n, seed=3, entropy_level=0, device=cuda), oracle.gen_entropy_and(n, 0, 3, 0)),
+        (gs.generate_enumerated_values(n, start=5, device=cuda), oracle.gen_enumerated(n, 5)),
+    ]
+    for got, want in cases:
+        assert np.array_equal(to_u32(got), want)
+    k = oracle.gen_uniform(n, 7)
+    inv, s, x = gs.check_sorted(to_dev(np.sort(k), cuda))
+    assert inv == 0 and (s, x) == oracle.multiset_checksum(k)
+    assert gs.check_sorted(to_dev(k, cuda))[0] == oracle.count_inversions_adjacent(k)
