@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Gkeys/s sorting 2^30 uint32 keys on MI355X.
+
+Contract (one JSON line on rank 0):
+  python bench.py --gpus N --steps K --warmup W
+  N = 1 : BASELINE.json configs[1] -- LSB radix sort, 2^30 uniform-random u32 keys, keys-only.
+  N > 1 : configs[4] shape -- MSB bucket-sharded sort, 2^30 keys per GPU, one RCCL all-to-all
+          (launched by torch.distributed.run, one rank per GPU).
+A "step" is one complete sort of one batch of synthetic keys already resident in HBM.  Every
+step sorts its own pre-generated input buffer (seed = step index), so no restore copy sits in
+the timed region (the reference restores inputs outside its timed call, lsb/sort.cu:141-146).
+
+Also reported on the same line:
+  roofline     -- the dominant kernel (lsb_downsweep): algorithmic bytes per launch
+                  (8 B/key x keys per launch) / its average launch duration,
+                  measured live with hipEvents on the launch stream during the timed steps.
+  cpu_baseline -- the reference's CPU check sort (std::sort) timed on this host on a bounded
+                  sample of the same workload (oracle/cpu_baseline.cpp; checker only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+LSB_BYTES_PER_KEY = {False: 48, True: 80}       # (4 + 8) x 4 passes; pairs (4 + 16) x 4
+DOWNSWEEP_BYTES_PER_KEY = {False: 8, True: 16}  # read + write keys (+ values) per launch
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=30, help="keys per GPU = 2^log2n (headline: 30)")
+    ap.add_argument("--pairs", action="store_true", help="configs[2]: key + value pairs")
+    ap.add_argument("--algo", choices=["lsb", "msb"], default=None)
+    ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log2", type=int, default=27)
+    ap.add_argument("--verify", action="store_true", help="device-side sortedness + checksum on every step")
+    return ap.parse_args()
+
+
+def load_pmc_traffic():
+    """HBM bytes per downsweep launch from the committed rocprofv3 --pmc summary, or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def cpu_baseline(n_log2, pairs):
+    from oracle import oracle as O
+    n = 1 << n_log2
+    keys = O.gen_uniform(n, seed=0)
+    if pairs:
+        dt, _, _ = O.time_std_stable_sort_pairs(keys, O.gen_enumerated(n))
+        what = "std::stable_sort of (key,value) structs"
+    else:
+        dt, _ = O.time_std_sort(keys)
+        what = "std::sort"
+    out = {"value": n / dt / 1e9, "unit": "Gkeys/s", "cores": 1, "kind": "port",
+           "sample": f"first 2^{n_log2} keys of the step-0 input (uniform splitmix64, seed 0), {what}, 1 thread, {dt:.2f} s",
+           "host_threads_available": O.hardware_threads()}
+    if not pairs:
+        dt_mt, used, _ = O.time_std_sort_mt(keys, 0)
+        out["all_cores"] = {"value": n / dt_mt / 1e9, "unit": "Gkeys/s", "cores": used,
+                            "sample": f"same 2^{n_log2} keys, {used} threads std::sort + inplace_merge tree, {dt_mt:.2f} s"}
+    return out
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import gpu_sort_amd as gs
+
+    n = 1 << args.log2n
+    algo = args.algo or ("lsb" if world == 1 else "msb")
+    steps, warmup = args.steps, args.warmup
+    total = steps + warmup
+
+    gen = gs.generate_uniform_keys if args.dist == "uniform" else gs.generate_zipf_keys
+    # one input buffer per step (4 GiB each at 2^30): nothing but the sort runs in the timed region
+    inputs = [gen(n, seed=i, start=rank * n, device=dev) for i in range(total)]
+    alt = torch.empty(n, dtype=torch.int32, device=dev)
+    vals = vals_alt = None
+    if args.pairs:
+        vals = [gs.generate_enumerated_values(n, device=dev) for _ in range(total)]
+        vals_alt = torch.empty(n, dtype=torch.int32, device=dev)
+
+    if world > 1:
+        from gpu_sort_amd import sharded
+        runner = sharded.ShardedSorter(n, args.pairs, dev)
+        nbytes = 0
+        temp = None
+    elif algo == "lsb":
+        nbytes = gs.lib.gs_lsb_temp_bytes(n, int(args.pairs))
+        temp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    else:
+        nbytes = gs.lib.gs_msb_temp_bytes(n, int(args.pairs))
+        temp = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+
+    checks = []
+
+    def one_step(i):
+        if world > 1:
+            out = runner.sort(inputs[i], vals[i] if args.pairs else None)
+            if args.verify:
+                checks.append(runner.verify(out))
+            return
+        if algo == "lsb":
+            dk = gs.DoubleBuffer(inputs[i], alt)
+            if args.pairs:
+                dv = gs.DoubleBuffer(vals[i], vals_alt)
+                gs.DeviceRadixSort.SortPairs(temp, nbytes, dk, dv, n, key_type=gs.GS_KEY_U32)
+            else:
+                gs.DeviceRadixSort.SortKeys(temp, nbytes, dk, n, key_type=gs.GS_KEY_U32)
+            res = dk.Current()
+        else:
+            seq = gs.rdxsrt_unstable_sort(inputs[i], vals[i] if args.pairs else None, n, alt, vals_alt,
+                                          pre_allocated_dm=temp, synchronize=False)
+            res = seq.sorted_keys
+        if args.verify:
+            checks.append(res)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    pre = None
+    if args.verify and world == 1:
+        pre = [gs.check_sorted(inputs[i])[1:] for i in range(total)]
+
+    for i in range(warmup):
+        one_step(i)
+    barrier()
+    prof = gs.KernelProfile()
+    t0 = time.perf_counter()
+    with prof:
+        for i in range(warmup, total):
+            one_step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernels = prof.read()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    verified = None
+    if args.verify and world == 1:
+        verified = True
+        for j, res in enumerate(checks):
+            inv, s, x = gs.check_sorted(res)
+            verified = verified and inv == 0 and (s, x) == pre[j]
+    elif args.verify:
+        verified = all(checks)
+
+    if rank == 0:
+        keys_total = n * world * steps
+        value = keys_total / elapsed / 1e9
+        ms_per_step = elapsed / steps * 1e3
+        dom = "lsb_downsweep" if algo == "lsb" and world == 1 else ("msb_partition" if "msb_partition" in kernels else None)
+        roofline = None
+        if dom and dom in kernels:
+            ms, cnt = kernels[dom]
+            avg_ms = ms / cnt
+            alg_bytes = DOWNSWEEP_BYTES_PER_KEY[args.pairs] * n
+            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            pmc = load_pmc_traffic()
+            traffic = None
+            if pmc and pmc.get("kernel") == dom and pmc.get("log2n") == args.log2n and bool(pmc.get("pairs")) == args.pairs:
+                traffic = pmc.get("hbm_bytes_per_launch")
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
+                        "launches": cnt}
+        whole = None
+        if algo == "lsb" and world == 1:
+            gbs = LSB_BYTES_PER_KEY[args.pairs] * n / (ms_per_step * 1e-3) / 1e9
+            whole = {"algorithmic_bytes_per_key": LSB_BYTES_PER_KEY[args.pairs], "achieved_GBps": round(gbs, 1),
+                     "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+                     "logical_GBps_cub_style": round(8 * n / (ms_per_step * 1e-3) / 1e9, 1)}
+        cpu = None
+        if not args.no_cpu_baseline and world >= 1:
+            cpu = cpu_baseline(min(args.cpu_sample_log2, args.log2n), args.pairs)
+        line = {
+            "metric": "Gkeys/s sorting 2^30 uint32 keys; achieved HBM GB/s vs roofline",
+            "value": round(value, 3), "unit": "Gkeys/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": (f"{algo}_radix_sort_2^{args.log2n}_u32_{args.dist}_"
+                                    f"{'pairs' if args.pairs else 'keys_only'}" + ("_per_gpu_sharded" if world > 1 else "")),
+                       "keys_per_gpu": n, "has_values": args.pairs, "algorithm": algo,
+                       "distribution": args.dist, "parallelism": "single" if world == 1 else f"msb_bucket_shard{world}"},
+            "roofline": roofline, "whole_sort": whole, "cpu_baseline": cpu,
+            "kernels_ms_total": {k: [round(v[0], 3), v[1]] for k, v in kernels.items()},
+        }
+        if verified is not None:
+            line["verified"] = bool(verified)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

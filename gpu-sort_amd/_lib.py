@@ -34,7 +34,14 @@ SIGNATURES = {
     "gs_generate_u32": (i32, [vp, u64, i32, u64, u64, i32, vp]),
     "gs_check_sorted_u32": (i32, [vp, u64, i32, vp, vp]),
     "gs_check_pairs_enumerated_u32": (i32, [vp, vp, vp, u64, vp, vp]),
+    "gs_profile_create": (vp, []),
+    "gs_profile_destroy": (None, [vp]),
+    "gs_profile_begin": (None, [vp]),
+    "gs_profile_end": (None, []),
+    "gs_profile_read": (i32, [vp, C.POINTER(C.c_double), C.POINTER(u64)]),
+    "gs_kernel_name": (C.c_char_p, [i32]),
 }
+GS_K_COUNT = 9
 
 
 class GpuSortError(RuntimeError):
@@ -69,3 +76,34 @@ def error_string(code):
 def check(code, what):
     if code != 0:
         raise GpuSortError(code, what)
+
+
+class KernelProfile:
+    """Per-kernel hipEvent timing on the launch stream (gs_profile_* in gpusort.h).
+
+    with KernelProfile() as prof: ...sorts...; prof.read() -> {name: (total_ms, launches)}"""
+
+    def __init__(self):
+        self._p = lib.gs_profile_create()
+
+    def __enter__(self):
+        lib.gs_profile_begin(self._p)
+        return self
+
+    def __exit__(self, *exc):
+        lib.gs_profile_end()
+        return False
+
+    def read(self):
+        ms = (C.c_double * GS_K_COUNT)()
+        cnt = (u64 * GS_K_COUNT)()
+        check(lib.gs_profile_read(self._p, ms, cnt), "gs_profile_read")
+        return {lib.gs_kernel_name(i).decode(): (ms[i], int(cnt[i])) for i in range(GS_K_COUNT) if cnt[i]}
+
+    def close(self):
+        if self._p:
+            lib.gs_profile_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        self.close()

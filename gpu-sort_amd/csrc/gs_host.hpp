@@ -7,3 +7,28 @@
 #include <stdint.h>
 
 #include "gpusort.h"
+
+#include <vector>
+
+// Per-kernel event timing (see gs_profile_* in gpusort.h).  KernelTimer brackets
+// one launch with an event pair when a profile is bound to this thread; it is a
+// no-op (two pointer compares) otherwise.
+struct gs_profile {
+    struct Span { int id; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    double ms[GS_K_COUNT] = {0};
+    uint64_t launches[GS_K_COUNT] = {0};
+};
+
+namespace gs {
+extern thread_local gs_profile *tl_profile;
+
+struct KernelTimer {
+    gs_profile *p;
+    hipStream_t s;
+    gs_profile::Span span;
+    KernelTimer(int id, hipStream_t stream);
+    ~KernelTimer();
+};
+}  // namespace gs

@@ -294,6 +294,7 @@ static inline size_t spine_bytes(uint64_t n) { return align256((size_t)RADIX * l
 int lsb_upsweep(const uint32_t *keys, uint32_t *spine, const PassParams &p, hipStream_t s)
 {
     const bool vec = ((uintptr_t)keys & 15u) == 0;
+    KernelTimer kt(GS_K_LSB_UPSWEEP, s);
     if (vec) hipLaunchKernelGGL(lsb_upsweep_kernel<true>, dim3(p.grid), dim3(LSB_THREADS), 0, s, keys, spine, p);
     else hipLaunchKernelGGL(lsb_upsweep_kernel<false>, dim3(p.grid), dim3(LSB_THREADS), 0, s, keys, spine, p);
     return (int)hipGetLastError();
@@ -301,6 +302,7 @@ int lsb_upsweep(const uint32_t *keys, uint32_t *spine, const PassParams &p, hipS
 
 int lsb_scan(uint32_t *spine, uint32_t *totals, uint32_t grid, hipStream_t s)
 {
+    KernelTimer kt(GS_K_LSB_SCAN, s);
     hipLaunchKernelGGL(lsb_scan_kernel, dim3(RADIX), dim3(256), 0, s, spine, totals, grid);
     return (int)hipGetLastError();
 }
@@ -308,6 +310,7 @@ int lsb_scan(uint32_t *spine, uint32_t *totals, uint32_t grid, hipStream_t s)
 int lsb_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, const uint32_t *spine,
                   const uint32_t *totals, const PassParams &p, hipStream_t s)
 {
+    KernelTimer kt(GS_K_LSB_DOWNSWEEP, s);
     if (vin)
         hipLaunchKernelGGL(lsb_downsweep_kernel<true>, dim3(p.grid), dim3(LSB_THREADS), 0, s, kin, kout, vin, vout,
                            spine, totals, p);

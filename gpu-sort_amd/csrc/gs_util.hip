@@ -102,11 +102,81 @@ static inline uint32_t stream_grid(uint64_t n)
 
 }  // namespace gs
 
+namespace gs {
+thread_local gs_profile *tl_profile = nullptr;
+
+static hipEvent_t take_event(gs_profile *p)
+{
+    hipEvent_t e;
+    if (!p->pool.empty()) { e = p->pool.back(); p->pool.pop_back(); return e; }
+    hipEventCreate(&e);
+    return e;
+}
+
+KernelTimer::KernelTimer(int id, hipStream_t stream) : p(tl_profile), s(stream)
+{
+    if (!p) return;
+    span.id = id;
+    span.a = take_event(p);
+    span.b = take_event(p);
+    hipEventRecord(span.a, s);
+}
+KernelTimer::~KernelTimer()
+{
+    if (!p) return;
+    hipEventRecord(span.b, s);
+    p->spans.push_back(span);
+}
+}  // namespace gs
+
 using namespace gs;
 
 extern "C" {
 
 int gs_version(void) { return GS_VERSION; }
+
+gs_profile *gs_profile_create(void) { return new gs_profile(); }
+
+void gs_profile_destroy(gs_profile *p)
+{
+    if (!p) return;
+    if (tl_profile == p) tl_profile = nullptr;
+    for (auto &sp : p->spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
+    for (auto e : p->pool) hipEventDestroy(e);
+    delete p;
+}
+
+void gs_profile_begin(gs_profile *p) { tl_profile = p; }
+void gs_profile_end(void) { tl_profile = nullptr; }
+
+int gs_profile_read(gs_profile *p, double total_ms[GS_K_COUNT], uint64_t launches[GS_K_COUNT])
+{
+    if (!p) return hipErrorInvalidValue;
+    for (auto &sp : p->spans) {
+        hipError_t e = hipEventSynchronize(sp.b);
+        if (e != hipSuccess) return (int)e;
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, sp.a, sp.b);
+        if (e != hipSuccess) return (int)e;
+        p->ms[sp.id] += ms;
+        p->launches[sp.id] += 1;
+        p->pool.push_back(sp.a);
+        p->pool.push_back(sp.b);
+    }
+    p->spans.clear();
+    for (int i = 0; i < GS_K_COUNT; ++i) {
+        if (total_ms) total_ms[i] = p->ms[i];
+        if (launches) launches[i] = p->launches[i];
+    }
+    return hipSuccess;
+}
+
+const char *gs_kernel_name(int id)
+{
+    static const char *names[GS_K_COUNT] = {"lsb_upsweep", "lsb_scan", "lsb_downsweep", "msb_histogram", "msb_classify",
+                                            "msb_partition", "msb_local_sort", "shard", "other"};
+    return (id >= 0 && id < GS_K_COUNT) ? names[id] : "?";
+}
 
 const char *gs_error_string(int err) { return hipGetErrorString((hipError_t)err); }
 

@@ -143,6 +143,28 @@ int gs_check_pairs_enumerated_u32(const uint32_t *d_keys_in, const uint32_t *d_k
                                   const uint32_t *d_vals, uint64_t num_items,
                                   uint64_t *d_result, void *stream);
 
+/* ------------------------------------------------------ kernel timing hook --
+ * Optional per-kernel device timing with hipEvents recorded on the SAME stream
+ * the kernels are launched on (replaces the reference's cudaEvent pairs,
+ * lsb/gpu_utils.h:3-11, and its gated per-pass BM_* events,
+ * msb/src/sort/gpu_radix_sort.h:266-269).  While a profile is bound to the
+ * calling thread (gs_profile_begin .. gs_profile_end) every kernel the library
+ * launches from that thread is bracketed by an event pair.  gs_profile_read
+ * waits for the recorded events and accumulates milliseconds and launch counts
+ * per kernel id; it may be called once the work has been enqueued.            */
+enum gs_kernel_id {
+    GS_K_LSB_UPSWEEP = 0, GS_K_LSB_SCAN = 1, GS_K_LSB_DOWNSWEEP = 2,
+    GS_K_MSB_HISTOGRAM = 3, GS_K_MSB_CLASSIFY = 4, GS_K_MSB_PARTITION = 5, GS_K_MSB_LOCAL_SORT = 6,
+    GS_K_SHARD = 7, GS_K_OTHER = 8, GS_K_COUNT = 9
+};
+typedef struct gs_profile gs_profile;
+gs_profile *gs_profile_create(void);
+void        gs_profile_destroy(gs_profile *p);
+void        gs_profile_begin(gs_profile *p);   /* bind to this thread */
+void        gs_profile_end(void);              /* unbind              */
+int         gs_profile_read(gs_profile *p, double total_ms[GS_K_COUNT], uint64_t launches[GS_K_COUNT]);
+const char *gs_kernel_name(int kernel_id);
+
 #ifdef __cplusplus
 }
 #endif
