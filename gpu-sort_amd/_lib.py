@@ -23,7 +23,7 @@ SIGNATURES = {
     "gs_error_string": (C.c_char_p, [i32]),
     "gs_lsb_temp_bytes": (sz, [u64, i32]),
     "gs_lsb_sort_u32": (i32, [vp, sz, pp, pp, C.POINTER(i32), u64, i32, i32, i32, i32, vp]),
-    "gs_lsb_geometry": (None, [u64, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "gs_lsb_geometry": (None, [u64, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gs_lsb_upsweep_u32": (i32, [vp, vp, u64, i32, i32, i32, i32, vp]),
     "gs_lsb_scan_spine": (i32, [vp, vp, u64, i32, vp]),
     "gs_lsb_downsweep_u32": (i32, [vp, vp, vp, vp, vp, vp, u64, i32, i32, i32, i32, i32, vp]),
@@ -101,9 +101,12 @@ class KernelProfile:
         return {lib.gs_kernel_name(i).decode(): (ms[i], int(cnt[i])) for i in range(GS_K_COUNT) if cnt[i]}
 
     def close(self):
-        if self._p:
+        if self._p and lib is not None:
             lib.gs_profile_destroy(self._p)
-            self._p = None
+        self._p = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -31,18 +31,58 @@ __device__ __forceinline__ uint32_t twiddle_out(uint32_t k, int f32, uint32_t x)
 }
 
 // Lanes of this wave whose 8-bit digit equals mine (all 64 lanes must be
-// active).  One ballot per digit bit; the per-lane select keeps the lanes that
-// agree with my bit.
-__device__ __forceinline__ uint64_t match_digit(uint32_t d)
+// active), as two 32-bit mask halves.  Per digit bit: v_bfe_i32 replicates my
+// bit to 32 bits (s), v_cmp ballots it into an SGPR pair (m), and one
+// v_bitop3_b32 per half keeps the lanes that agree with me:
+// p & ~(m ^ s), truth table 0x90 for (p, m, s).  32 VALU in all.  The stream is
+// software-pipelined over two SGPR pairs so every ballot is read at least two
+// instructions after the v_cmp that wrote it (VALU-write-SGPR -> VALU-read
+// hazard on gfx950; nothing pads hazards inside an asm statement).
+__device__ __forceinline__ void match_digit(uint32_t d, uint32_t &lo, uint32_t &hi)
 {
-    uint64_t peers = ~0ull;
-#pragma unroll
-    for (int b = 0; b < RADIX_BITS; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t m = __ballot(bit);
-        peers &= bit ? m : ~m;
-    }
-    return peers;
+    uint32_t t0, t1, t2;
+    asm volatile(
+        "v_bfe_i32 %[t0], %[d], 0, 1\n\t"
+        "v_bfe_i32 %[t1], %[d], 1, 1\n\t"
+        "v_cmp_ne_u32_e64 s[92:93], 0, %[t0]\n\t"
+        "v_cmp_ne_u32_e64 s[94:95], 0, %[t1]\n\t"
+        "v_bfe_i32 %[t2], %[d], 2, 1\n\t"
+        "v_xnor_b32 %[lo], s92, %[t0]\n\t"
+        "v_xnor_b32 %[hi], s93, %[t0]\n\t"
+        "v_cmp_ne_u32_e64 s[92:93], 0, %[t2]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s94, %[t1] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s95, %[t1] bitop3:0x90\n\t"
+        "v_bfe_i32 %[t0], %[d], 3, 1\n\t"
+        "v_cmp_ne_u32_e64 s[94:95], 0, %[t0]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s92, %[t2] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s93, %[t2] bitop3:0x90\n\t"
+        "v_bfe_i32 %[t1], %[d], 4, 1\n\t"
+        "v_cmp_ne_u32_e64 s[92:93], 0, %[t1]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s94, %[t0] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s95, %[t0] bitop3:0x90\n\t"
+        "v_bfe_i32 %[t2], %[d], 5, 1\n\t"
+        "v_cmp_ne_u32_e64 s[94:95], 0, %[t2]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s92, %[t1] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s93, %[t1] bitop3:0x90\n\t"
+        "v_bfe_i32 %[t0], %[d], 6, 1\n\t"
+        "v_cmp_ne_u32_e64 s[92:93], 0, %[t0]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s94, %[t2] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s95, %[t2] bitop3:0x90\n\t"
+        "v_bfe_i32 %[t1], %[d], 7, 1\n\t"
+        "v_cmp_ne_u32_e64 s[94:95], 0, %[t1]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s92, %[t0] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s93, %[t0] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s94, %[t1] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s95, %[t1] bitop3:0x90"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+        : [d] "v"(d)
+        : "s92", "s93", "s94", "s95");
+}
+
+// rank of my lane among the set lanes of (hi:lo)
+__device__ __forceinline__ uint32_t count_lower(uint32_t lo, uint32_t hi)
+{
+    return __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
 }
 
 // popcount of `mask` restricted to lanes below mine
@@ -51,15 +91,19 @@ __device__ __forceinline__ uint32_t count_lower(uint64_t mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// inclusive wave scan (64 lanes)
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+// inclusive wave scan (64 lanes) with DPP row shifts / row broadcasts: seven
+// VALU ops, no LDS traffic.  update_dpp(old=0, ...) yields 0 for lanes whose
+// source lane is outside the row or that are masked off by row/bank masks.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
 {
-    const int lane = lane_id();
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        uint32_t t = __shfl_up(v, o, WAVE);
-        if (lane >= o) v += t;
-    }
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false);  // row_shr:3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);  // row_shr:4, banks 1-3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);  // row_shr:8, banks 2-3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
     return v;
 }
 

@@ -135,8 +135,8 @@ def lsb_pass_kernels(keys_in, vals_in, shift, bits, descending=False, stream=Non
 
     Returns dict(spine_counts, spine_scanned, totals, keys_out, vals_out, grid, tile)."""
     n = keys_in.numel()
-    g, t = C.c_uint32(), C.c_uint32()
-    lib.gs_lsb_geometry(n, int(vals_in is not None), C.byref(g), C.byref(t))
+    g, t, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    lib.gs_lsb_geometry(n, int(vals_in is not None), C.byref(g), C.byref(t), C.byref(c))
     dev = keys_in.device
     spine = torch.zeros(256 * g.value, dtype=torch.int32, device=dev)
     totals = torch.zeros(256, dtype=torch.int32, device=dev)
@@ -154,4 +154,4 @@ def lsb_pass_kernels(keys_in, vals_in, shift, bits, descending=False, stream=Non
                                    spine.data_ptr(), totals.data_ptr(), n, shift, bits, int(descending),
                                    _lib.GS_KEY_U32, _lib.GS_KEY_U32, sp), "gs_lsb_downsweep_u32")
     return dict(spine_counts=counts, spine_scanned=spine, totals=totals, keys_out=keys_out, vals_out=vals_out,
-                grid=g.value, tile=t.value)
+                grid=g.value, tile=t.value, tiles_per_chunk=c.value)

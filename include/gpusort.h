@@ -68,10 +68,13 @@ int gs_lsb_sort_u32(void *d_temp, size_t temp_bytes,
                     int descending, int key_type, void *stream);
 
 /* Bring-up / test access to the three kernels of one pass (SURVEY.md 8a rows
- * L4-L6): upsweep -> spine[digit*grid + block]; scan -> exclusive in place +
- * totals; downsweep -> scatter.  `grid`/`tile` report the launch geometry
- * the library uses for num_items so the oracle can mirror it.               */
-void gs_lsb_geometry(uint64_t num_items, int has_values, uint32_t *grid, uint32_t *tile);
+ * L4-L6): upsweep -> spine[digit*grid + chunk]; scan -> exclusive in place +
+ * totals; downsweep -> scatter.  gs_lsb_geometry reports the decomposition the
+ * library uses for num_items so the oracle can mirror it: `tile` keys per
+ * tile, chunk c = tiles [c*tiles_per_chunk, (c+1)*tiles_per_chunk), `grid`
+ * chunks in all.                                                            */
+void gs_lsb_geometry(uint64_t num_items, int has_values, uint32_t *grid, uint32_t *tile,
+                     uint32_t *tiles_per_chunk);
 int  gs_lsb_upsweep_u32(const uint32_t *d_keys_in, uint32_t *d_spine, uint64_t num_items,
                         int shift, int bits, int descending, int key_type_in, void *stream);
 int  gs_lsb_scan_spine(uint32_t *d_spine, uint32_t *d_totals, uint64_t num_items,

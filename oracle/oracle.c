@@ -233,13 +233,14 @@ void orc_lsb_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in,
 
 /* ------------------------------------------------------ per-kernel goldens */
 
-void orc_even_share(uint64_t num_tiles, uint32_t grid, uint32_t b,
-                    uint64_t *tile_begin, uint64_t *tile_end)
+void orc_chunk_tiles(uint64_t num_tiles, uint32_t tiles_per_chunk, uint32_t c,
+                     uint64_t *tile_begin, uint64_t *tile_end)
 {
-    uint64_t q = num_tiles / grid, rem = num_tiles % grid;
-    uint64_t lo = (uint64_t)b * q + (b < rem ? b : rem);
+    uint64_t lo = (uint64_t)c * tiles_per_chunk, hi = lo + tiles_per_chunk;
+    if (lo > num_tiles) lo = num_tiles;
+    if (hi > num_tiles) hi = num_tiles;
     *tile_begin = lo;
-    *tile_end = lo + q + (b < rem ? 1 : 0);
+    *tile_end = hi;
 }
 
 static inline uint32_t digit_of(uint32_t key, int shift, int bits, int descending)
@@ -249,14 +250,14 @@ static inline uint32_t digit_of(uint32_t key, int shift, int bits, int descendin
 }
 
 void orc_upsweep(const uint32_t *keys, uint64_t n, int shift, int bits, int descending,
-                 uint32_t tile, uint32_t grid, uint32_t *spine)
+                 uint32_t tile, uint32_t tiles_per_chunk, uint32_t grid, uint32_t *spine)
 {
     uint64_t num_tiles = (n + tile - 1) / tile;
     uint32_t radix = 1u << bits;
     memset(spine, 0, (size_t)radix * grid * sizeof(uint32_t));
     for (uint32_t b = 0; b < grid; ++b) {
         uint64_t t0, t1;
-        orc_even_share(num_tiles, grid, b, &t0, &t1);
+        orc_chunk_tiles(num_tiles, tiles_per_chunk, b, &t0, &t1);
         uint64_t lo = t0 * tile, hi = t1 * tile;
         if (hi > n) hi = n;
         for (uint64_t i = lo; i < hi; ++i)

@@ -71,13 +71,14 @@ void orc_lsb_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in,
 /* ---- per-kernel goldens for the three-kernel pass (derived; semantics of
  *      agent_radix_sort_upsweep.cuh:215-229, dispatch_radix_sort.cuh:102-148,
  *      agent_radix_sort_downsweep.cuh:560-566) --------------------------- */
-/* even-share tile->block split (grid_even_share.cuh:103-139 restated):
- * blocks [0,rem) get q+1 tiles, the rest q; returns tile range of block b */
-void orc_even_share(uint64_t num_tiles, uint32_t grid, uint32_t b,
-                    uint64_t *tile_begin, uint64_t *tile_end);
-/* spine[d*grid + b] = count of digit d in block b's tiles */
+/* tile->chunk split (the role of GridEvenShare, grid_even_share.cuh:103-139:
+ * every block owns one contiguous run of tiles): chunk c = tiles
+ * [c*tiles_per_chunk, (c+1)*tiles_per_chunk) clipped to num_tiles */
+void orc_chunk_tiles(uint64_t num_tiles, uint32_t tiles_per_chunk, uint32_t c,
+                     uint64_t *tile_begin, uint64_t *tile_end);
+/* spine[d*grid + c] = count of digit d in chunk c's tiles */
 void orc_upsweep(const uint32_t *keys, uint64_t n, int shift, int bits, int descending,
-                 uint32_t tile, uint32_t grid, uint32_t *spine);
+                 uint32_t tile, uint32_t tiles_per_chunk, uint32_t grid, uint32_t *spine);
 /* in-place exclusive prefix sum over len ints */
 void orc_exclusive_scan(uint32_t *spine, uint64_t len);
 /* one stable counting pass on digit (key>>shift)&((1<<bits)-1) */

@@ -52,8 +52,8 @@ def lib():
         L.orc_lsb_reference_ranks.argtypes = [_u32p, u64, i32, i32, i32, _u32p]
         L.orc_lsb_sort_keys.argtypes = [_u32p, _u32p, u64, i32, i32, i32]
         L.orc_lsb_sort_pairs.argtypes = [_u32p, _u32p, _u32p, _u32p, u64, i32, i32, i32]
-        L.orc_even_share.argtypes = [u64, C.c_uint32, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
-        L.orc_upsweep.argtypes = [_u32p, u64, i32, i32, i32, C.c_uint32, C.c_uint32, _u32p]
+        L.orc_chunk_tiles.argtypes = [u64, C.c_uint32, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
+        L.orc_upsweep.argtypes = [_u32p, u64, i32, i32, i32, C.c_uint32, C.c_uint32, C.c_uint32, _u32p]
         L.orc_exclusive_scan.argtypes = [_u32p, u64]
         L.orc_downsweep.argtypes = [_u32p, p, _u32p, p, u64, i32, i32, i32]
         L.orc_lsd_radix_sort.argtypes = [_u32p, p, _u32p, p, u64, i32, i32, i32, C.POINTER(i32)]
@@ -135,14 +135,14 @@ def lsb_reference_ranks(keys, begin_bit=0, end_bit=32, descending=False):
     lib().orc_lsb_reference_ranks(keys, keys.size, begin_bit, end_bit, int(descending), r); return r
 
 
-def even_share(num_tiles, grid, b):
+def chunk_tiles(num_tiles, tiles_per_chunk, c):
     lo, hi = C.c_uint64(), C.c_uint64()
-    lib().orc_even_share(num_tiles, grid, b, C.byref(lo), C.byref(hi)); return lo.value, hi.value
+    lib().orc_chunk_tiles(num_tiles, tiles_per_chunk, c, C.byref(lo), C.byref(hi)); return lo.value, hi.value
 
 
-def upsweep(keys, shift, bits, tile, grid, descending=False):
+def upsweep(keys, shift, bits, tile, tiles_per_chunk, grid, descending=False):
     keys = _c(keys); spine = np.zeros((1 << bits) * grid, np.uint32)
-    lib().orc_upsweep(keys, keys.size, shift, bits, int(descending), tile, grid, spine); return spine
+    lib().orc_upsweep(keys, keys.size, shift, bits, int(descending), tile, tiles_per_chunk, grid, spine); return spine
 
 
 def exclusive_scan(spine):

@@ -60,14 +60,14 @@ def test_golden_fixtures(gs, cuda, golden):
 
 
 @pytest.mark.parametrize("shift,bits", [(0, 8), (8, 8), (24, 8), (29, 3)])
-@pytest.mark.parametrize("n", [1, 8191, 8192, 8193, 100003, 3 * 1024 * 8192 // 2 + 5])
+@pytest.mark.parametrize("n", [1, 8191, 8192, 8193, 100003, 3 * 1024 * 8192 // 2 + 5, 5 * 1024 * 8192 + 77])
 def test_three_kernels_of_one_pass(gs, cuda, oracle, n, shift, bits):
     """upsweep counts, spine scan and downsweep scatter each match their oracle."""
     keys = oracle.gen_uniform(n, seed=shift + 1)
     vals = oracle.gen_enumerated(n)
     r = gs.lsb_pass_kernels(to_dev(keys, cuda), to_dev(vals, cuda), shift, bits)
     torch.cuda.synchronize()
-    counts = oracle.upsweep(keys, shift, bits, r["tile"], r["grid"])
+    counts = oracle.upsweep(keys, shift, bits, r["tile"], r["tiles_per_chunk"], r["grid"])
     got = to_u32(r["spine_counts"]).reshape(256, r["grid"])[: 1 << bits].reshape(-1)
     assert np.array_equal(got, counts)
     # device spine is always 256 rows; rows >= 2^bits are zero

@@ -81,9 +81,9 @@ def test_oracle_vs_numpy(oracle, n):
 
 def test_per_kernel_goldens_compose(oracle):
     # upsweep -> scan -> (block, digit) bases reproduce the stable pass
-    n, tile, grid = 50000, 8192, 4
+    n, tile, tpc, grid = 50000, 8192, 2, 4
     keys = oracle.gen_uniform(n, seed=3)
-    counts = oracle.upsweep(keys, 8, 8, tile, grid)
+    counts = oracle.upsweep(keys, 8, 8, tile, tpc, grid)
     assert counts.sum() == n
     assert np.array_equal(counts.reshape(256, grid).sum(1), np.bincount((keys >> 8) & 0xFF, minlength=256))
     scanned = oracle.exclusive_scan(counts)
@@ -93,7 +93,7 @@ def test_per_kernel_goldens_compose(oracle):
     # block b's first key of digit d lands at scanned[d*grid+b]
     nt = (n + tile - 1) // tile
     for b in range(grid):
-        lo, hi = oracle.even_share(nt, grid, b)
+        lo, hi = oracle.chunk_tiles(nt, tpc, b)
         seg = keys[lo * tile: min(hi * tile, n)]
         for d in (0, 17, 255):
             idx = np.nonzero(((seg >> 8) & 0xFF) == d)[0]
