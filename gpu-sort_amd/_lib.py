@@ -24,9 +24,10 @@ SIGNATURES = {
     "gs_lsb_temp_bytes": (sz, [u64, i32]),
     "gs_lsb_sort_u32": (i32, [vp, sz, pp, pp, C.POINTER(i32), u64, i32, i32, i32, i32, vp]),
     "gs_lsb_geometry": (None, [u64, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
-    "gs_lsb_upsweep_u32": (i32, [vp, vp, u64, i32, i32, i32, i32, vp]),
-    "gs_lsb_scan_spine": (i32, [vp, vp, u64, i32, vp]),
-    "gs_lsb_downsweep_u32": (i32, [vp, vp, vp, vp, vp, vp, u64, i32, i32, i32, i32, i32, vp]),
+    "gs_lsb_workspace_layout": (i32, [vp, u64, pp, pp, pp]),
+    "gs_lsb_upsweep_u32": (i32, [vp, sz, vp, u64, i32, i32, i32, i32, vp]),
+    "gs_lsb_scan_spine": (i32, [vp, sz, u64, vp]),
+    "gs_lsb_downsweep_u32": (i32, [vp, sz, vp, vp, vp, vp, u64, i32, i32, i32, i32, i32, vp]),
     "gs_msb_temp_bytes": (sz, [u64, i32]),
     "gs_msb_sort_u32": (i32, [vp, sz, vp, vp, u64, vp, vp, pp, pp, i32, vp, i32]),
     "gs_shard_histogram_u32": (i32, [vp, u64, i32, vp, i32, vp]),

@@ -133,25 +133,39 @@ def sortKeysGPU(d_key_buf, d_key_alt_buf, num_items, key_type=None):
 def lsb_pass_kernels(keys_in, vals_in, shift, bits, descending=False, stream=None):
     """Run the three kernels of ONE pass separately (bring-up / parity of SURVEY.md rows L4-L6).
 
-    Returns dict(spine_counts, spine_scanned, totals, keys_out, vals_out, grid, tile)."""
+    Returns dict(spine_counts, prefix16, spine_scanned, totals, keys_out, vals_out, grid, tile, tiles_per_chunk)."""
+    import numpy as np
     n = keys_in.numel()
     g, t, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
     lib.gs_lsb_geometry(n, int(vals_in is not None), C.byref(g), C.byref(t), C.byref(c))
     dev = keys_in.device
-    spine = torch.zeros(256 * g.value, dtype=torch.int32, device=dev)
-    totals = torch.zeros(256, dtype=torch.int32, device=dev)
+    nbytes = lib.gs_lsb_temp_bytes(n, int(vals_in is not None))
+    temp = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    sp, tot, pf = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    lib.gs_lsb_workspace_layout(temp.data_ptr(), n, C.byref(sp), C.byref(tot), C.byref(pf))
+    base = temp.data_ptr()
+    num_tiles = (n + t.value - 1) // t.value
+
+    def view(ptr, count, dtype):
+        off = ptr.value - base
+        return temp[off: off + count * dtype.itemsize].cpu().numpy().view(dtype).copy()
+
     keys_out = torch.empty_like(keys_in)
     vals_out = torch.empty_like(vals_in) if vals_in is not None else None
-    sp = _stream_ptr(stream)
-    check(lib.gs_lsb_upsweep_u32(keys_in.data_ptr(), spine.data_ptr(), n, shift, bits, int(descending),
-                                 _lib.GS_KEY_U32, sp), "gs_lsb_upsweep_u32")
-    counts = spine.clone()
-    check(lib.gs_lsb_scan_spine(spine.data_ptr(), totals.data_ptr(), n, int(vals_in is not None), sp),
-          "gs_lsb_scan_spine")
-    check(lib.gs_lsb_downsweep_u32(keys_in.data_ptr(), keys_out.data_ptr(),
+    s = _stream_ptr(stream)
+    check(lib.gs_lsb_upsweep_u32(temp.data_ptr(), nbytes, keys_in.data_ptr(), n, shift, bits, int(descending),
+                                 _lib.GS_KEY_U32, s), "gs_lsb_upsweep_u32")
+    torch.cuda.synchronize()
+    counts = view(sp, 256 * g.value, np.dtype(np.uint32))
+    prefix16 = view(pf, num_tiles * 256, np.dtype(np.uint16))
+    check(lib.gs_lsb_scan_spine(temp.data_ptr(), nbytes, n, s), "gs_lsb_scan_spine")
+    torch.cuda.synchronize()
+    scanned = view(sp, 256 * g.value, np.dtype(np.uint32))
+    totals = view(tot, 256, np.dtype(np.uint32))
+    check(lib.gs_lsb_downsweep_u32(temp.data_ptr(), nbytes, keys_in.data_ptr(), keys_out.data_ptr(),
                                    vals_in.data_ptr() if vals_in is not None else None,
                                    vals_out.data_ptr() if vals_out is not None else None,
-                                   spine.data_ptr(), totals.data_ptr(), n, shift, bits, int(descending),
-                                   _lib.GS_KEY_U32, _lib.GS_KEY_U32, sp), "gs_lsb_downsweep_u32")
-    return dict(spine_counts=counts, spine_scanned=spine, totals=totals, keys_out=keys_out, vals_out=vals_out,
-                grid=g.value, tile=t.value, tiles_per_chunk=c.value)
+                                   n, shift, bits, int(descending), _lib.GS_KEY_U32, _lib.GS_KEY_U32, s),
+          "gs_lsb_downsweep_u32")
+    return dict(spine_counts=counts, prefix16=prefix16, spine_scanned=scanned, totals=totals, keys_out=keys_out,
+                vals_out=vals_out, grid=g.value, tile=t.value, tiles_per_chunk=c.value)

@@ -50,7 +50,8 @@ const char *gs_error_string(int err);
  * (lsb/cub/cub/device/device_radix_sort.cuh:248-272, 595-621, 754-780),
  * as called from lsb/sort.cu:36,42,59,65.                                   */
 
-/* Bytes of temp storage for a sort of num_items (spine + digit totals).
+/* Bytes of temp storage for a sort of num_items (spine, digit totals and the
+ * per-tile u16 prefixes: about 1.6 % of the key bytes).
  * Replaces the d_temp_storage==NULL size query
  * (dispatch_radix_sort.cuh:1094-1110).  has_values is accepted for symmetry;
  * like CUB with is_overwrite_okay the value path needs no extra scratch.    */
@@ -68,20 +69,26 @@ int gs_lsb_sort_u32(void *d_temp, size_t temp_bytes,
                     int descending, int key_type, void *stream);
 
 /* Bring-up / test access to the three kernels of one pass (SURVEY.md 8a rows
- * L4-L6): upsweep -> spine[digit*grid + chunk]; scan -> exclusive in place +
- * totals; downsweep -> scatter.  gs_lsb_geometry reports the decomposition the
- * library uses for num_items so the oracle can mirror it: `tile` keys per
- * tile, chunk c = tiles [c*tiles_per_chunk, (c+1)*tiles_per_chunk), `grid`
- * chunks in all.                                                            */
+ * L4-L6), all working on the same d_temp workspace (gs_lsb_temp_bytes):
+ *   upsweep   -> spine[digit*grid + chunk] (u32 counts per chunk of
+ *                tiles_per_chunk tiles) and prefix16[tile*256 + digit] (u16:
+ *                count of the digit in the chunk's earlier tiles);
+ *   scan      -> spine rows exclusive-scanned in place + totals[256];
+ *   downsweep -> stable scatter of one pass.
+ * gs_lsb_geometry reports the decomposition used for num_items so the oracle
+ * can mirror it; gs_lsb_workspace_layout reports where the three arrays live
+ * inside d_temp.                                                            */
 void gs_lsb_geometry(uint64_t num_items, int has_values, uint32_t *grid, uint32_t *tile,
                      uint32_t *tiles_per_chunk);
-int  gs_lsb_upsweep_u32(const uint32_t *d_keys_in, uint32_t *d_spine, uint64_t num_items,
-                        int shift, int bits, int descending, int key_type_in, void *stream);
-int  gs_lsb_scan_spine(uint32_t *d_spine, uint32_t *d_totals, uint64_t num_items,
-                       int has_values, void *stream);
-int  gs_lsb_downsweep_u32(const uint32_t *d_keys_in, uint32_t *d_keys_out,
+int  gs_lsb_workspace_layout(void *d_temp, uint64_t num_items, uint32_t **d_spine,
+                             uint32_t **d_totals, uint16_t **d_prefix16);
+int  gs_lsb_upsweep_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys_in,
+                        uint64_t num_items, int shift, int bits, int descending,
+                        int key_type_in, void *stream);
+int  gs_lsb_scan_spine(void *d_temp, size_t temp_bytes, uint64_t num_items, void *stream);
+int  gs_lsb_downsweep_u32(void *d_temp, size_t temp_bytes,
+                          const uint32_t *d_keys_in, uint32_t *d_keys_out,
                           const uint32_t *d_vals_in, uint32_t *d_vals_out,
-                          const uint32_t *d_spine, const uint32_t *d_totals,
                           uint64_t num_items, int shift, int bits, int descending,
                           int key_type_in, int key_type_out, void *stream);
 

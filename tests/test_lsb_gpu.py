@@ -68,13 +68,22 @@ def test_three_kernels_of_one_pass(gs, cuda, oracle, n, shift, bits):
     r = gs.lsb_pass_kernels(to_dev(keys, cuda), to_dev(vals, cuda), shift, bits)
     torch.cuda.synchronize()
     counts = oracle.upsweep(keys, shift, bits, r["tile"], r["tiles_per_chunk"], r["grid"])
-    got = to_u32(r["spine_counts"]).reshape(256, r["grid"])[: 1 << bits].reshape(-1)
-    assert np.array_equal(got, counts)
-    # device spine is always 256 rows; rows >= 2^bits are zero
-    assert to_u32(r["spine_counts"]).reshape(256, r["grid"])[1 << bits:].sum() == 0
+    got = r["spine_counts"].reshape(256, r["grid"])
+    assert np.array_equal(got[: 1 << bits].reshape(-1), counts)
+    assert got[1 << bits:].sum() == 0                      # device spine always has 256 rows
+    # prefix16[tile][d] = count of digit d in the chunk's earlier tiles
+    tile, tpc = r["tile"], r["tiles_per_chunk"]
+    num_tiles = (n + tile - 1) // tile
+    dig = (keys >> np.uint32(shift)) & np.uint32((1 << bits) - 1)
+    per_tile = np.stack([np.bincount(dig[t * tile:(t + 1) * tile], minlength=256) for t in range(num_tiles)])
+    want16 = np.zeros_like(per_tile)
+    for t in range(num_tiles):
+        c0 = (t // tpc) * tpc
+        want16[t] = per_tile[c0:t].sum(0)
+    assert np.array_equal(r["prefix16"].reshape(num_tiles, 256).astype(np.int64), want16)
     # scan: row-exclusive + totals; flattened exclusive scan == oracle's
-    tot = to_u32(r["totals"])
-    rows = to_u32(r["spine_scanned"]).reshape(256, r["grid"])
+    tot = r["totals"]
+    rows = r["spine_scanned"].reshape(256, r["grid"])
     flat = (rows + (np.cumsum(tot, dtype=np.uint64) - tot).astype(np.uint32)[:, None])[: 1 << bits].reshape(-1)
     assert np.array_equal(flat, oracle.exclusive_scan(counts))
     ko, vo = oracle.downsweep(keys, vals, shift, bits)
