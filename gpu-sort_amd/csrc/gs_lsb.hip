@@ -23,33 +23,10 @@
 //             2.05 ms per pass at 2^30 keys, against 3.2 ms for persistent
 //             blocks that each own a long run of tiles and march in lockstep.
 #include "gs_device.hpp"
-#include "gs_host.hpp"
+#include "gs_lsb.hpp"
 #include <cstdlib>
 
 namespace gs {
-
-constexpr int LSB_THREADS = 512;                     // 8 waves
-constexpr int LSB_WAVES = LSB_THREADS / WAVE;
-constexpr int LSB_KPT = 16;                          // keys per thread per tile
-constexpr int LSB_TILE = LSB_THREADS * LSB_KPT;      // 8192 keys = 32 KiB
-constexpr int LSB_CHUNK = LSB_WAVES;                 // tiles per chunk = waves per upsweep block
-constexpr int LSB_BLOCKS_PER_CU = 2;                 // <=128 VGPRs -> 4 waves/SIMD -> 2 blocks of 8 waves
-constexpr int MI355X_CUS = 256;
-constexpr int MI355X_XCDS = 8;
-constexpr uint32_t LSB_RESIDENT = MI355X_CUS * LSB_BLOCKS_PER_CU;   // downsweep blocks in flight
-
-struct PassParams {
-    uint32_t n;          // number of keys
-    uint32_t num_tiles;  // ceil(n / LSB_TILE)
-    uint32_t grid;       // chunks = upsweep blocks = spine row length
-    uint32_t ds_grid;    // downsweep blocks = full tiles
-    uint32_t shift;      // digit = (key >> shift) & mask
-    uint32_t bits;       // digit width (<= 8)
-    uint32_t mask;
-    int f32_in, f32_out;          // float twiddle on read / undo on write
-    uint32_t xor_in, xor_out;     // uniform xor on read / write (sign flip, descending)
-    uint32_t valu_rounds;         // bit i set: round i matches with VALU ballots, else through LDS
-};
 
 // ---------------------------------------------------------------- upsweep --
 template <bool VEC>
@@ -388,7 +365,7 @@ static inline uint32_t lsb_ds_grid(uint64_t n)
     return full ? full : 1u;
 }
 
-static void twiddle_masks(int key_type, int descending, bool first, bool last, PassParams &p)
+void lsb_twiddle_masks(int key_type, int descending, bool first, bool last, PassParams &p)
 {
     // keys are stored twiddled between passes; the first pass maps in, the last maps out
     const uint32_t sign = (key_type == GS_KEY_I32) ? 0x80000000u : 0u;
@@ -399,7 +376,7 @@ static void twiddle_masks(int key_type, int descending, bool first, bool last, P
     p.xor_out = last ? (sign ^ flip) : 0u;
 }
 
-static PassParams make_params(uint64_t n, int shift, int bits)
+PassParams lsb_make_params(uint64_t n, int shift, int bits)
 {
     PassParams p{};
     p.n = (uint32_t)n;
@@ -419,12 +396,8 @@ static inline size_t spine_bytes(uint64_t n) { return align256((size_t)RADIX * l
 static inline size_t totals_bytes() { return align256(RADIX * sizeof(uint32_t)); }
 static inline size_t prefix16_bytes(uint64_t n) { return align256((size_t)lsb_num_tiles(n) * RADIX * sizeof(uint16_t)); }
 
-struct LsbWorkspace {
-    uint32_t *spine;
-    uint32_t *totals;
-    uint16_t *prefix16;
-};
-static LsbWorkspace carve(void *temp, uint64_t n)
+size_t lsb_temp_bytes(uint64_t n) { return spine_bytes(n) + totals_bytes() + prefix16_bytes(n); }
+LsbWorkspace lsb_carve(void *temp, uint64_t n)
 {
     char *c = (char *)temp;
     LsbWorkspace ws;
@@ -484,7 +457,7 @@ extern "C" {
 
 size_t gs_lsb_temp_bytes(uint64_t num_items, int /*has_values*/)
 {
-    return spine_bytes(num_items) + totals_bytes() + prefix16_bytes(num_items);
+    return lsb_temp_bytes(num_items);
 }
 
 void gs_lsb_geometry(uint64_t num_items, int /*has_values*/, uint32_t *grid, uint32_t *tile, uint32_t *tiles_per_chunk)
@@ -500,9 +473,9 @@ int gs_lsb_upsweep_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys_i
     if (num_items >= (1ull << 32) || bits < 1 || bits > 8 || shift < 0 || shift + bits > 32) return hipErrorInvalidValue;
     if (!d_temp || temp_bytes < gs_lsb_temp_bytes(num_items, 0)) return hipErrorInvalidValue;
     if (num_items == 0) return hipSuccess;
-    PassParams p = make_params(num_items, shift, bits);
-    twiddle_masks(key_type_in, descending, true, true, p);
-    const LsbWorkspace ws = carve(d_temp, num_items);
+    PassParams p = lsb_make_params(num_items, shift, bits);
+    lsb_twiddle_masks(key_type_in, descending, true, true, p);
+    const LsbWorkspace ws = lsb_carve(d_temp, num_items);
     return lsb_upsweep(d_keys_in, ws.spine, ws.prefix16, p, (hipStream_t)stream);
 }
 
@@ -511,7 +484,7 @@ int gs_lsb_scan_spine(void *d_temp, size_t temp_bytes, uint64_t num_items, void 
     if (num_items >= (1ull << 32)) return hipErrorInvalidValue;
     if (!d_temp || temp_bytes < gs_lsb_temp_bytes(num_items, 0)) return hipErrorInvalidValue;
     if (num_items == 0) return hipSuccess;
-    const LsbWorkspace ws = carve(d_temp, num_items);
+    const LsbWorkspace ws = lsb_carve(d_temp, num_items);
     return lsb_scan(ws.spine, ws.totals, lsb_grid(num_items), (hipStream_t)stream);
 }
 
@@ -523,13 +496,13 @@ int gs_lsb_downsweep_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys
     if ((d_vals_in == nullptr) != (d_vals_out == nullptr)) return hipErrorInvalidValue;
     if (!d_temp || temp_bytes < gs_lsb_temp_bytes(num_items, 0)) return hipErrorInvalidValue;
     if (num_items == 0) return hipSuccess;
-    PassParams p = make_params(num_items, shift, bits);
+    PassParams p = lsb_make_params(num_items, shift, bits);
     PassParams in{}, out{};
-    twiddle_masks(key_type_in, descending, true, false, in);
-    twiddle_masks(key_type_out, descending, false, true, out);
+    lsb_twiddle_masks(key_type_in, descending, true, false, in);
+    lsb_twiddle_masks(key_type_out, descending, false, true, out);
     p.f32_in = in.f32_in; p.xor_in = in.xor_in;
     p.f32_out = out.f32_out; p.xor_out = out.xor_out;
-    const LsbWorkspace ws = carve(d_temp, num_items);
+    const LsbWorkspace ws = lsb_carve(d_temp, num_items);
     return lsb_downsweep(d_keys_in, d_keys_out, d_vals_in, d_vals_out, ws.spine, ws.prefix16, ws.totals, p,
                          (hipStream_t)stream);
 }
@@ -537,7 +510,7 @@ int gs_lsb_downsweep_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys
 int gs_lsb_workspace_layout(void *d_temp, uint64_t num_items, uint32_t **d_spine, uint32_t **d_totals,
                             uint16_t **d_prefix16)
 {
-    const LsbWorkspace ws = carve(d_temp, num_items);
+    const LsbWorkspace ws = lsb_carve(d_temp, num_items);
     if (d_spine) *d_spine = ws.spine;
     if (d_totals) *d_totals = ws.totals;
     if (d_prefix16) *d_prefix16 = ws.prefix16;
@@ -556,15 +529,15 @@ int gs_lsb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], uint32
     if (!d_keys[0] || !d_keys[1] || (d_vals && (!d_vals[0] || !d_vals[1]))) return hipErrorInvalidValue;
 
     hipStream_t s = (hipStream_t)stream;
-    const LsbWorkspace ws = carve(d_temp, num_items);
+    const LsbWorkspace ws = lsb_carve(d_temp, num_items);
     const int num_bits = end_bit - begin_bit;
     const int num_passes = (num_bits + RADIX_BITS - 1) / RADIX_BITS;
     int sel = *selector;
     for (int pass = 0; pass < num_passes; ++pass) {
         const int shift = begin_bit + pass * RADIX_BITS;
         const int bits = (end_bit - shift < RADIX_BITS) ? end_bit - shift : RADIX_BITS;
-        PassParams p = make_params(num_items, shift, bits);
-        twiddle_masks(key_type, descending, pass == 0, pass == num_passes - 1, p);
+        PassParams p = lsb_make_params(num_items, shift, bits);
+        lsb_twiddle_masks(key_type, descending, pass == 0, pass == num_passes - 1, p);
         const uint32_t *kin = d_keys[sel];
         uint32_t *kout = d_keys[sel ^ 1];
         const uint32_t *vin = d_vals ? d_vals[sel] : nullptr;

@@ -1,0 +1,48 @@
+// gs_lsb.hpp -- geometry, pass parameters and host entry points of the LSB
+// three-kernel pass, shared with the MSB driver (its top-byte partition is one
+// LSB pass at shift 24).
+#pragma once
+
+#include "gs_host.hpp"
+
+namespace gs {
+
+constexpr int LSB_THREADS = 512;                     // 8 waves
+constexpr int LSB_WAVES = LSB_THREADS / WAVE;
+constexpr int LSB_KPT = 16;                          // keys per thread per tile
+constexpr int LSB_TILE = LSB_THREADS * LSB_KPT;      // 8192 keys = 32 KiB
+constexpr int LSB_CHUNK = LSB_WAVES;                 // tiles per chunk = waves per upsweep block
+constexpr int LSB_BLOCKS_PER_CU = 2;                 // <=128 VGPRs -> 4 waves/SIMD -> 2 blocks of 8 waves
+constexpr int MI355X_CUS = 256;
+constexpr int MI355X_XCDS = 8;
+constexpr uint32_t LSB_RESIDENT = MI355X_CUS * LSB_BLOCKS_PER_CU;   // downsweep blocks in flight
+
+struct PassParams {
+    uint32_t n;          // number of keys
+    uint32_t num_tiles;  // ceil(n / LSB_TILE)
+    uint32_t grid;       // chunks = upsweep blocks = spine row length
+    uint32_t ds_grid;    // downsweep blocks = full tiles
+    uint32_t shift;      // digit = (key >> shift) & mask
+    uint32_t bits;       // digit width (<= 8)
+    uint32_t mask;
+    int f32_in, f32_out;          // float twiddle on read / undo on write
+    uint32_t xor_in, xor_out;     // uniform xor on read / write (sign flip, descending)
+    uint32_t valu_rounds;         // bit i set: round i matches with VALU ballots, else through LDS
+};
+
+struct LsbWorkspace {
+    uint32_t *spine;
+    uint32_t *totals;
+    uint16_t *prefix16;
+};
+
+size_t lsb_temp_bytes(uint64_t n);
+LsbWorkspace lsb_carve(void *temp, uint64_t n);
+PassParams lsb_make_params(uint64_t n, int shift, int bits);
+void lsb_twiddle_masks(int key_type, int descending, bool first, bool last, PassParams &p);
+int lsb_upsweep(const uint32_t *keys, uint32_t *spine, uint16_t *prefix16, const PassParams &p, hipStream_t s);
+int lsb_scan(uint32_t *spine, uint32_t *totals, uint32_t grid, hipStream_t s);
+int lsb_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, const uint32_t *spine,
+                  const uint16_t *prefix16, const uint32_t *totals, const PassParams &p, hipStream_t s);
+
+}  // namespace gs

@@ -1,12 +1,556 @@
-// gs_msb.hip -- placeholder until the MSB hybrid path lands (next commit).
+// gs_msb.hip -- unstable MSD hybrid radix sort for gfx950 (MI355X), ascending.
+//
+// Replaces (behaviour, not code) rdxsrt_unstable_sort and its kernels
+// (msb/src/sort/gpu_radix_sort.h:197-507, msb/src/sort/cuda_radix_sort.h,
+// msb/src/sort/gpu_radix_sort.cu):
+//   - most-significant byte first; a bucket that fits one workgroup's LDS is
+//     finished there by a local LSD sort on its remaining bits and written
+//     straight to the result buffer (M7), bigger buckets are partitioned on
+//     their next byte (M3 histogram, M4 offsets + classification, M6 scatter);
+//   - adjacent tiny sub-buckets are merged into one local-sort task while their
+//     sum stays below 3000 keys and re-sorted on one more byte (M4 rules,
+//     cuda_radix_sort.h:1084-1087, cuda_radix_sort_config.h:9);
+//   - values are only defined up to permutation inside equal keys (unstable);
+//   - for 32-bit keys the result ends in the caller's INPUT arrays
+//     (gpu_radix_sort.h:359-360).
+//
+// What is different by design (MI355X-first):
+//   - the whole schedule lives on the device: bucket lists, tile prefixes and
+//     task lists are built by the classify kernel with atomics, and every level
+//     launches fixed upper-bound grids whose surplus blocks exit at once; the
+//     reference's three blocking device->host round trips per pass
+//     (gpu_radix_sort.cu:31-49) are gone, and so are its 8 cudaMallocs per call
+//     (one caller-provided workspace);
+//   - the top-byte partition is one stable LSB pass (gs_lsb.hip) at shift 24;
+//   - 160 KiB of LDS per CU lets a workgroup finish buckets of up to 17408 keys
+//     (reference: 9216), so uniform 2^30 keys need two partitions + one local
+//     sort = 32 B/key of HBM traffic (reference thresholds: 44 B/key);
+//   - ranking inside the local sort is the wave64 ballot/popcount match of the
+//     LSB path; the scatter of an unstable partition ranks with LDS atomics.
 #include "gs_device.hpp"
-#include "gs_host.hpp"
+#include "gs_lsb.hpp"
+
+namespace gs {
+
+constexpr int MSB_THREADS = 512;
+constexpr int MSB_WAVES = MSB_THREADS / WAVE;
+constexpr int MSB_KPT = 16;
+constexpr int MSB_TILE = MSB_THREADS * MSB_KPT;    // 8192 keys per partition tile
+constexpr int MSB_NCLASS = 4;                      // local-sort size classes (reference: 7-9 configs)
+constexpr uint32_t MSB_MERGE = 3000;               // merge adjacent sub-buckets while the sum is below this
+constexpr uint32_t MSB_MAX_GRID = 16384;           // blocks per launch; kernels stride over longer lists
+// keys per thread of each class (x 512 threads = capacity): 2048, 4608, 9216, 17408
+__host__ __device__ constexpr int msb_class_kpt(int c) { return c == 0 ? 4 : c == 1 ? 9 : c == 2 ? 18 : 34; }
+__host__ __device__ constexpr uint32_t msb_class_cap(int c) { return (uint32_t)msb_class_kpt(c) * MSB_THREADS; }
+// pairs keep {key,value} in LDS, so their largest class is 9216 (144 KiB would not leave room for two blocks)
+__host__ __device__ constexpr int msb_num_classes(bool has_values) { return has_values ? 3 : 4; }
+
+struct MsbBucket { uint32_t offset, size, tile_start, pad; };   // a bucket still to be partitioned
+struct MsbTask { uint32_t offset, size, sort_bits, pad; };      // a range to finish with a local sort
+struct MsbLevel {
+    unsigned long long packed;           // hi32: buckets to partition at this level, lo32: their tiles
+    uint32_t task_count[MSB_NCLASS];     // local-sort tasks emitted by this level's classification
+    uint32_t pad[2];
+};
+
+struct MsbWs {
+    MsbLevel *level;                     // [5]
+    MsbBucket *buckets[2];               // level L uses buckets[L & 1]
+    uint32_t *hist[2];                   // [max_buckets][256]: counts, then scatter cursors
+    MsbTask *tasks[MSB_NCLASS];
+    uint32_t max_buckets, max_tasks;
+};
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline uint32_t msb_max_buckets(uint64_t n, bool has_values)
+{
+    return (uint32_t)(n / msb_class_cap(msb_num_classes(has_values) - 1)) + RADIX + 1;
+}
+static inline uint32_t msb_max_tasks(uint64_t n, bool has_values)
+{
+    // a task is either >= MSB_MERGE keys or is followed by something that did not fit: <= 2n/MERGE,
+    // plus up to 256 per partitioned bucket
+    return (uint32_t)(2 * n / MSB_MERGE) + msb_max_buckets(n, has_values) + 2 * RADIX;
+}
+static size_t msb_ws_bytes(uint64_t n, bool has_values)
+{
+    const size_t mb = msb_max_buckets(n, has_values), mt = msb_max_tasks(n, has_values);
+    return align256(5 * sizeof(MsbLevel)) + 2 * align256(mb * sizeof(MsbBucket)) + 2 * align256(mb * RADIX * sizeof(uint32_t)) +
+           MSB_NCLASS * align256(mt * sizeof(MsbTask));
+}
+static MsbWs msb_carve(void *temp, uint64_t n, bool has_values)
+{
+    MsbWs ws;
+    ws.max_buckets = msb_max_buckets(n, has_values);
+    ws.max_tasks = msb_max_tasks(n, has_values);
+    char *c = (char *)temp;
+    ws.level = (MsbLevel *)c; c += align256(5 * sizeof(MsbLevel));
+    for (int i = 0; i < 2; ++i) { ws.buckets[i] = (MsbBucket *)c; c += align256((size_t)ws.max_buckets * sizeof(MsbBucket)); }
+    for (int i = 0; i < 2; ++i) { ws.hist[i] = (uint32_t *)c; c += align256((size_t)ws.max_buckets * RADIX * sizeof(uint32_t)); }
+    for (int i = 0; i < MSB_NCLASS; ++i) { ws.tasks[i] = (MsbTask *)c; c += align256((size_t)ws.max_tasks * sizeof(MsbTask)); }
+    return ws;
+}
+
+// ------------------------------------------------------------------- init --
+__global__ void msb_init_kernel(MsbWs ws, uint32_t n)
+{
+    const int t = threadIdx.x;
+    if (t < 5) {
+        MsbLevel z{};
+        if (t == 0) z.packed = (1ull << 32) | ((n + MSB_TILE - 1) / MSB_TILE);
+        ws.level[t] = z;
+    }
+    if (t == 0) ws.buckets[0][0] = MsbBucket{0u, n, 0u, 0u};
+}
+
+// direct path for arrays that fit one workgroup: a single task on all 32 bits
+__global__ void msb_single_task_kernel(MsbWs ws, uint32_t n, int cls)
+{
+    if (threadIdx.x == 0) {
+        ws.tasks[cls][0] = MsbTask{0u, n, 32u, 0u};
+        ws.level[0].task_count[cls] = 1;
+    }
+}
+
+// bucket that owns global tile index g (buckets are appended with increasing tile_start)
+__device__ __forceinline__ uint32_t msb_find_bucket(const MsbBucket *__restrict__ b, uint32_t count, uint32_t g)
+{
+    uint32_t lo = 0, hi = count;          // last entry with tile_start <= g
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (b[mid].tile_start <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// -------------------------------------------------------------- histogram --
+// M3: 256-bin histogram of byte `shift/8` for every tile of every bucket of level L,
+// accumulated per bucket with one global atomic per non-empty bin and tile.
+__global__ __launch_bounds__(MSB_THREADS) void msb_hist_kernel(MsbWs ws, int L, const uint32_t *__restrict__ src, int shift)
+{
+    __shared__ uint32_t lh[MSB_WAVES][RADIX];
+    const unsigned long long packed = ws.level[L].packed;
+    const uint32_t nb = (uint32_t)(packed >> 32), ntiles = (uint32_t)packed;
+    const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    const MsbBucket *bk = ws.buckets[L & 1];
+    uint32_t *my = lh[w];
+    for (uint32_t g = blockIdx.x; g < ntiles; g += gridDim.x) {
+        const uint32_t b = msb_find_bucket(bk, nb, g);
+        const MsbBucket B = bk[b];
+        const uint32_t lo = B.offset + (g - B.tile_start) * MSB_TILE;
+        const uint32_t end = B.offset + B.size;
+        const uint32_t len = (end - lo < (uint32_t)MSB_TILE) ? end - lo : (uint32_t)MSB_TILE;
+#pragma unroll
+        for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
+        const uint32_t *p = src + lo;
+        for (uint32_t i = (uint32_t)w * WAVE + lane; i < len; i += MSB_THREADS)
+            atomicAdd(&my[(p[i] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (tid < RADIX) {
+            uint32_t s = 0;
+#pragma unroll
+            for (int j = 0; j < MSB_WAVES; ++j) s += lh[j][tid];
+            if (s) atomicAdd(&ws.hist[L & 1][(size_t)b * RADIX + tid], s);
+        }
+        __syncthreads();
+    }
+}
+
+// --------------------------------------------------------------- classify --
+// M4: per bucket of level L turn the 256 counts into absolute sub-bucket offsets
+// (the scatter's cursors) and decide what happens to every sub-bucket next:
+//   empty                      -> nothing
+//   > largest local capacity   -> bucket of level L+1 (partitioned on the next byte)
+//   otherwise                  -> local-sort task; adjacent sub-buckets are merged
+//                                 greedily while the running sum is < MSB_MERGE and
+//                                 still fits (a merged task also re-sorts this byte).
+// LAST (byte 0): only the cursors are needed, the scatter finishes everything.
+// `counts0`: level 0 reads the LSB pass's digit totals instead of hist[0].
+template <bool LAST>
+__global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, const uint32_t *__restrict__ counts0, int nclass)
+{
+    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t s_cnt[RADIX], s_abs[RADIX], s_task[RADIX], s_nsub[RADIX];
+    __shared__ uint8_t s_large[RADIX];
+    const uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
+    const int d = threadIdx.x;
+    const uint32_t cap_max = msb_class_cap(nclass - 1);
+    const uint32_t rb = 24u - 8u * (uint32_t)L;                  // bits below this level's byte
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const MsbBucket B = ws.buckets[L & 1][b];
+        uint32_t *row = ws.hist[L & 1] + (size_t)b * RADIX;
+        const uint32_t c = (L == 0) ? counts0[d] : row[d];
+        const uint32_t ex = block_exclusive_scan_256(c, scratch, nullptr);
+        const uint32_t abs = B.offset + ex;
+        if (L > 0) row[d] = abs;
+        if (LAST) continue;
+        s_cnt[d] = c; s_abs[d] = abs; s_task[d] = 0; s_nsub[d] = 0; s_large[d] = 0;
+        __syncthreads();
+        if (d == 0) {
+            int run_start = -1;
+            uint32_t run_sum = 0, run_nsub = 0;
+            for (int q = 0; q < RADIX; ++q) {
+                const uint32_t cq = s_cnt[q];
+                if (cq == 0) continue;
+                if (cq > cap_max) {
+                    if (run_start >= 0) { s_task[run_start] = run_sum; s_nsub[run_start] = run_nsub; run_start = -1; }
+                    s_large[q] = 1;
+                    continue;
+                }
+                if (run_start >= 0 && run_sum < MSB_MERGE && run_sum + cq <= cap_max) {
+                    run_sum += cq; ++run_nsub;
+                } else {
+                    if (run_start >= 0) { s_task[run_start] = run_sum; s_nsub[run_start] = run_nsub; }
+                    run_start = q; run_sum = cq; run_nsub = 1;
+                }
+            }
+            if (run_start >= 0) { s_task[run_start] = run_sum; s_nsub[run_start] = run_nsub; }
+        }
+        __syncthreads();
+        uint32_t new_bucket = 0xffffffffu;
+        if (s_large[d]) {
+            const uint32_t tiles = (c + MSB_TILE - 1) / MSB_TILE;
+            const unsigned long long old = atomicAdd(&ws.level[L + 1].packed, (1ull << 32) | tiles);
+            new_bucket = (uint32_t)(old >> 32);
+            ws.buckets[(L + 1) & 1][new_bucket] = MsbBucket{abs, c, (uint32_t)old, 0u};
+        } else if (s_task[d]) {
+            const uint32_t size = s_task[d];
+            int cls = 0;
+            while (msb_class_cap(cls) < size) ++cls;
+            const uint32_t ti = atomicAdd(&ws.level[L].task_count[cls], 1u);
+            ws.tasks[cls][ti] = MsbTask{abs, size, rb + (s_nsub[d] > 1 ? 8u : 0u), 0u};
+        }
+        // clear the histogram rows of the buckets just created (all threads help)
+        s_cnt[d] = new_bucket;
+        __syncthreads();
+        for (int q = 0; q < RADIX; ++q) {
+            const uint32_t nbk = s_cnt[q];
+            if (nbk != 0xffffffffu) ws.hist[(L + 1) & 1][(size_t)nbk * RADIX + d] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- scatter --
+// M6: unstable counting-sort scatter of one tile on byte `shift/8`.  Ranks inside the
+// tile come from LDS atomics (one fetch-add per key, a single one per wave when all 64
+// lanes hold the same digit -- the hot-bucket case), the tile's slice of every
+// sub-bucket is reserved with one global atomic per digit (M6: inter-block order is
+// not deterministic), and the keys go through LDS so each digit run is written with
+// consecutive lanes on consecutive addresses.
+template <bool HAS_VALUES>
+__global__ __launch_bounds__(MSB_THREADS, 4) void msb_scatter_kernel(MsbWs ws, int L, const uint32_t *__restrict__ src_k,
+                                                                    uint32_t *__restrict__ dst_k,
+                                                                    const uint32_t *__restrict__ src_v,
+                                                                    uint32_t *__restrict__ dst_v, int shift, int f32_out,
+                                                                    uint32_t xor_out)
+{
+    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t lcnt[RADIX], lex[RADIX], gbase[RADIX];
+    __shared__ uint32_t stage[MSB_TILE * (HAS_VALUES ? 2 : 1)];
+    const unsigned long long packed = ws.level[L].packed;
+    const uint32_t nb = (uint32_t)(packed >> 32), ntiles = (uint32_t)packed;
+    const int tid = threadIdx.x, lane = lane_id();
+    const MsbBucket *bk = ws.buckets[L & 1];
+    for (uint32_t g = blockIdx.x; g < ntiles; g += gridDim.x) {
+    const uint32_t b = msb_find_bucket(bk, nb, g);
+    const MsbBucket B = bk[b];
+    const uint32_t lo = B.offset + (g - B.tile_start) * MSB_TILE;
+    const uint32_t end = B.offset + B.size;
+    const uint32_t valid = (end - lo < (uint32_t)MSB_TILE) ? end - lo : (uint32_t)MSB_TILE;
+
+    uint32_t key[MSB_KPT], val[MSB_KPT], rnk[MSB_KPT];
+#pragma unroll
+    for (int i = 0; i < MSB_KPT; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * MSB_THREADS;
+        key[i] = (idx < valid) ? src_k[lo + idx] : 0u;
+        if (HAS_VALUES) val[i] = (idx < valid) ? src_v[lo + idx] : 0u;
+    }
+    if (tid < RADIX) lcnt[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MSB_KPT; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * MSB_THREADS;
+        const bool ok = idx < valid;
+        const uint32_t d = (key[i] >> shift) & 255u;
+        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+        if (__builtin_amdgcn_ballot_w64(ok && d == d0) == ~0ull) {
+            // whole wave on one digit: one atomic for 64 keys
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&lcnt[d0], 64u);
+            rnk[i] = __builtin_amdgcn_readfirstlane(base) + (uint32_t)lane;
+        } else {
+            rnk[i] = ok ? atomicAdd(&lcnt[d], 1u) : 0u;
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t c = (tid < RADIX) ? lcnt[tid] : 0u;
+        const uint32_t ex = block_exclusive_scan_256(c, scratch, nullptr);
+        if (tid < RADIX) {
+            const uint32_t base = c ? atomicAdd(&ws.hist[L & 1][(size_t)b * RADIX + tid], c) : 0u;
+            lex[tid] = ex;
+            gbase[tid] = base - ex;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MSB_KPT; ++i) {
+        const uint32_t idx = (uint32_t)tid + i * MSB_THREADS;
+        if (idx < valid) {
+            const uint32_t at = lex[(key[i] >> shift) & 255u] + rnk[i];
+            if (HAS_VALUES) reinterpret_cast<uint2 *>(stage)[at] = make_uint2(key[i], val[i]);
+            else stage[at] = key[i];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MSB_KPT; ++i) {
+        const uint32_t slot = (uint32_t)tid + i * MSB_THREADS;
+        if (slot < valid) {
+            uint32_t k, v = 0;
+            if (HAS_VALUES) {
+                const uint2 kv = reinterpret_cast<const uint2 *>(stage)[slot];
+                k = kv.x; v = kv.y;
+            } else {
+                k = stage[slot];
+            }
+            const uint32_t dst = gbase[(k >> shift) & 255u] + slot;
+            dst_k[dst] = twiddle_out(k, f32_out, xor_out);
+            if (HAS_VALUES) dst_v[dst] = v;
+        }
+    }
+    __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------- local sort --
+// M7: finish one range of <= KPT*512 keys inside a workgroup: stable LSD passes of 8
+// bits over its low `sort_bits` bits, entirely in registers + LDS, then one coalesced
+// store to the result buffer.  Ranking per pass is the LSB downsweep's: wave64
+// ballot/popcount match + wave-private LDS histogram, wave 0 scans the 8 histograms.
+template <int KPT, bool HAS_VALUES>
+struct LocalSmem {
+    uint32_t whist[MSB_WAVES][RADIX];
+    uint32_t stage[KPT * MSB_THREADS * (HAS_VALUES ? 2 : 1)];
+};
+
+template <int KPT, bool HAS_VALUES>
+__global__ __launch_bounds__(MSB_THREADS, 4) void msb_local_sort_kernel(MsbWs ws, int L, int cls,
+                                                                       const uint32_t *__restrict__ src_k,
+                                                                       uint32_t *__restrict__ dst_k,
+                                                                       const uint32_t *__restrict__ src_v,
+                                                                       uint32_t *__restrict__ dst_v, int f32_in,
+                                                                       uint32_t xor_in, int f32_out, uint32_t xor_out)
+{
+    __shared__ __attribute__((aligned(16))) LocalSmem<KPT, HAS_VALUES> sm;
+    const uint32_t ntasks = ws.level[L].task_count[cls];
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    uint32_t *my = sm.whist[w];
+    const uint32_t wbase = (uint32_t)w * (WAVE * KPT) + lane;
+    for (uint32_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
+    const MsbTask T = ws.tasks[cls][ti];
+
+    uint32_t key[KPT], val[HAS_VALUES ? KPT : 1], pos[KPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const uint32_t idx = wbase + i * WAVE;
+        key[i] = 0xffffffffu;                       // padding sorts last (keys are in twiddled form)
+        if (idx < T.size) key[i] = twiddle_in(src_k[T.offset + idx], f32_in, xor_in);
+        if (HAS_VALUES) val[i] = (idx < T.size) ? src_v[T.offset + idx] : 0u;
+    }
+
+    for (uint32_t shift = 0; shift < T.sort_bits; shift += 8) {
+#pragma unroll
+        for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t d = (key[i] >> shift) & 255u;
+            uint32_t plo, phi;
+            match_digit(d, plo, phi);
+            const uint32_t lower = count_lower(plo, phi);
+            pos[i] = my[d] + lower;
+            if (lower == 0)
+                __hip_atomic_fetch_add(&my[d], (uint32_t)(__popc(plo) + __popc(phi)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]), "+v"(key[i]));
+        __syncthreads();
+        if (w == 0) {
+            uint32_t run[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < MSB_WAVES; ++j) {
+                const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
+                run[0] += x.x; run[1] += x.y; run[2] += x.z; run[3] += x.w;
+            }
+            const uint32_t lane_sum = run[0] + run[1] + run[2] + run[3];
+            uint4 e4;
+            e4.x = wave_inclusive_scan(lane_sum) - lane_sum;
+            e4.y = e4.x + run[0];
+            e4.z = e4.y + run[1];
+            e4.w = e4.z + run[2];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < MSB_WAVES; ++j) {
+                const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
+                reinterpret_cast<uint4 *>(sm.whist[j])[lane] = e4;
+                e4.x += x.x; e4.y += x.y; e4.z += x.z; e4.w += x.w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t at = pos[i] + my[(key[i] >> shift) & 255u];
+            if (HAS_VALUES) reinterpret_cast<uint2 *>(sm.stage)[at] = make_uint2(key[i], val[i]);
+            else sm.stage[at] = key[i];
+        }
+        __syncthreads();
+        if (shift + 8 < T.sort_bits) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t idx = wbase + i * WAVE;
+                if (HAS_VALUES) {
+                    const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[idx];
+                    key[i] = kv.x; val[i] = kv.y;
+                } else {
+                    key[i] = sm.stage[idx];
+                }
+            }
+            // the next pass rewrites `stage` only after its two barriers
+        }
+    }
+    for (uint32_t j = tid; j < T.size; j += MSB_THREADS) {
+        if (HAS_VALUES) {
+            const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[j];
+            dst_k[T.offset + j] = twiddle_out(kv.x, f32_out, xor_out);
+            dst_v[T.offset + j] = kv.y;
+        } else {
+            dst_k[T.offset + j] = twiddle_out(sm.stage[j], f32_out, xor_out);
+        }
+    }
+    __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------- host --
+
+template <bool HAS_VALUES>
+static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uint32_t *sk, uint32_t *dk, const uint32_t *sv,
+                               uint32_t *dv, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out, hipStream_t s)
+{
+    KernelTimer kt(GS_K_MSB_LOCAL_SORT, s);
+    const dim3 block(MSB_THREADS);
+    const uint32_t grid = bound < MSB_MAX_GRID ? bound : MSB_MAX_GRID;   // grid-stride over the task list
+    hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_kpt(0), HAS_VALUES>), dim3(grid), block, 0, s, ws, L, 0, sk, dk, sv,
+                       dv, f32_in, xor_in, f32_out, xor_out);
+    hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_kpt(1), HAS_VALUES>), dim3(grid), block, 0, s, ws, L, 1, sk, dk, sv,
+                       dv, f32_in, xor_in, f32_out, xor_out);
+    hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_kpt(2), HAS_VALUES>), dim3(grid), block, 0, s, ws, L, 2, sk, dk, sv,
+                       dv, f32_in, xor_in, f32_out, xor_out);
+    if (!HAS_VALUES)
+        hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_kpt(3), false>), dim3(grid), block, 0, s, ws, L, 3, sk, dk, sv,
+                           dv, f32_in, xor_in, f32_out, xor_out);
+}
+
+}  // namespace gs
+
+using namespace gs;
 
 extern "C" {
-size_t gs_msb_temp_bytes(uint64_t, int) { return 0; }
-int gs_msb_sort_u32(void *, size_t, uint32_t *, uint32_t *, uint64_t, uint32_t *, uint32_t *, uint32_t **, uint32_t **,
-                    int, void *, int) { return hipErrorNotSupported; }
+
+size_t gs_msb_temp_bytes(uint64_t num_items, int has_values)
+{
+    return align256(lsb_temp_bytes(num_items)) + msb_ws_bytes(num_items, has_values != 0);
+}
+
+int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t *d_vals, uint64_t num_items,
+                    uint32_t *d_keys_alt, uint32_t *d_vals_alt, uint32_t **d_sorted_keys, uint32_t **d_sorted_vals,
+                    int key_type, void *stream, int synchronize)
+{
+    if (num_items >= (1ull << 32)) return hipErrorInvalidValue;
+    if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;
+    if (d_sorted_keys) *d_sorted_keys = d_keys;       // 32-bit keys: result in the input arrays
+    if (d_sorted_vals) *d_sorted_vals = d_vals;
+    if (num_items == 0) return hipSuccess;
+    const bool pairs = d_vals != nullptr;
+    if (!d_keys || !d_keys_alt || (pairs && !d_vals_alt)) return hipErrorInvalidValue;
+    if (!d_temp || temp_bytes < gs_msb_temp_bytes(num_items, pairs)) return hipErrorInvalidValue;
+
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t n = (uint32_t)num_items;
+    const int nclass = msb_num_classes(pairs);
+    const MsbWs ws = msb_carve((char *)d_temp + align256(lsb_temp_bytes(num_items)), num_items, pairs);
+    const LsbWorkspace lw = lsb_carve(d_temp, num_items);
+
+    // key twiddles: the first reader maps in, every final writer maps out
+    PassParams tw{};
+    lsb_twiddle_masks(key_type, 0, true, true, tw);
+
+    { KernelTimer kt(GS_K_OTHER, s); hipLaunchKernelGGL(msb_init_kernel, dim3(1), dim3(64), 0, s, ws, n); }
+
+    if (n <= msb_class_cap(nclass - 1)) {
+        // fits one workgroup: one local sort on all 32 bits, in place
+        int cls = 0;
+        while (msb_class_cap(cls) < n) ++cls;
+        hipLaunchKernelGGL(msb_single_task_kernel, dim3(1), dim3(64), 0, s, ws, n, cls);
+        if (pairs) launch_local_sorts<true>(ws, 0, 1, d_keys, d_keys, d_vals, d_vals, tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out, s);
+        else launch_local_sorts<false>(ws, 0, 1, d_keys, d_keys, nullptr, nullptr, tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out, s);
+    } else {
+        const uint32_t tiles_all = (n + MSB_TILE - 1) / MSB_TILE;
+        uint32_t *buf_k[2] = {d_keys, d_keys_alt};
+        uint32_t *buf_v[2] = {d_vals, d_vals_alt};
+        // level 0: the top byte with one stable LSB pass, IN -> ALT (keys stay twiddled)
+        PassParams p0 = lsb_make_params(num_items, 24, 8);
+        lsb_twiddle_masks(key_type, 0, true, false, p0);
+        int e;
+        if ((e = lsb_upsweep(d_keys, lw.spine, lw.prefix16, p0, s))) return e;
+        if ((e = lsb_scan(lw.spine, lw.totals, p0.grid, s))) return e;
+        { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
+          hipLaunchKernelGGL(msb_classify_kernel<false>, dim3(1), dim3(256), 0, s, ws, 0, (const uint32_t *)lw.totals, nclass); }
+        if ((e = lsb_downsweep(d_keys, d_keys_alt, d_vals, d_vals_alt, lw.spine, lw.prefix16, lw.totals, p0, s))) return e;
+        // upper bounds of what a level can hold (surplus blocks exit immediately)
+        const uint32_t max_tasks_lvl = ws.max_tasks;
+        const uint32_t task_grid0 = max_tasks_lvl < 2u * RADIX ? max_tasks_lvl : 2u * RADIX;   // level 0 emits <= 256 tasks
+        if (pairs) launch_local_sorts<true>(ws, 0, task_grid0, d_keys_alt, d_keys, d_vals_alt, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s);
+        else launch_local_sorts<false>(ws, 0, task_grid0, d_keys_alt, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s);
+
+        for (int L = 1; L <= 3; ++L) {
+            const int shift = 24 - 8 * L;
+            uint32_t *sk = buf_k[L & 1], *dk = buf_k[(L + 1) & 1];
+            uint32_t *sv = buf_v[L & 1], *dv = buf_v[(L + 1) & 1];
+            // buckets at level L: <= 256 at level 1, else bounded by size; tiles: n/T + one ragged tile per bucket
+            const uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
+            const uint32_t max_tiles_ub = tiles_all + max_b;
+            const uint32_t max_tiles = max_tiles_ub < MSB_MAX_GRID ? max_tiles_ub : MSB_MAX_GRID;
+            const bool last = (L == 3);
+            { KernelTimer kt(GS_K_MSB_HISTOGRAM, s);
+              hipLaunchKernelGGL(msb_hist_kernel, dim3(max_tiles), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, shift); }
+            { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
+              const uint32_t cg = max_b < 4096u ? max_b : 4096u;
+              if (last) hipLaunchKernelGGL(msb_classify_kernel<true>, dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass);
+              else hipLaunchKernelGGL(msb_classify_kernel<false>, dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass); }
+            { KernelTimer kt(GS_K_MSB_PARTITION, s);
+              if (pairs)
+                  hipLaunchKernelGGL(msb_scatter_kernel<true>, dim3(max_tiles), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, dk,
+                                     (const uint32_t *)sv, dv, shift, last ? tw.f32_out : 0, last ? tw.xor_out : 0u);
+              else
+                  hipLaunchKernelGGL(msb_scatter_kernel<false>, dim3(max_tiles), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, dk,
+                                     (const uint32_t *)nullptr, (uint32_t *)nullptr, shift, last ? tw.f32_out : 0, last ? tw.xor_out : 0u); }
+            if (!last) {
+                if (pairs) launch_local_sorts<true>(ws, L, max_tasks_lvl, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s);
+                else launch_local_sorts<false>(ws, L, max_tasks_lvl, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s);
+            }
+        }
+    }
+    int err = (int)hipGetLastError();
+    if (err) return err;
+    if (synchronize) err = (int)hipStreamSynchronize(s);
+    return err;
+}
+
 int gs_shard_histogram_u32(const uint32_t *, uint64_t, int, uint64_t *, int, void *) { return hipErrorNotSupported; }
 int gs_shard_partition_u32(void *, size_t, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint64_t, int,
                            const uint8_t *, int, uint64_t *, int, void *) { return hipErrorNotSupported; }
-}
+
+}  // extern "C"

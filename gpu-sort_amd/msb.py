@@ -42,9 +42,9 @@ def rdxsrt_unstable_sort(dev_keys, dev_values, key_count, dev_sorted_keys_out, d
     check(err, "gs_msb_sort_u32")
 
     def which(ptr, a, b):
-        if ptr is None or ptr == 0:
-            return None
-        return a if ptr == a.data_ptr() else b
+        if ptr is None or ptr == 0 or ptr == a.data_ptr():   # empty tensors have a null data_ptr
+            return a
+        return b
 
     return RDXSRT_SortedSequence(which(sk.value, dev_keys, dev_sorted_keys_out),
                                  which(sv.value, dev_values, dev_sorted_values_out) if has_values else None)

@@ -1,0 +1,157 @@
+"""GPU parity tests for the MSB path (gs_msb_sort_u32 through the C ABI).
+
+Model: msb/tests/test_sort_keys.cu and test_sort_pairs.cu -- 12 entropy levels
+{1..11, 0} (:126), constant and swept problem sizes (:154-195), keys compared
+bit-exact with a sorted reference (:56-59), values either secondary-sorted inside
+equal-key runs (:80-109) or, for enumerated values, checked through the
+value->key map and the sum (:141-146,166-176), because the sort is unstable.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import to_dev, to_u32
+
+pytestmark = pytest.mark.gpu
+
+ENTROPY_LEVELS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 0]
+
+
+def _msb_keys(gs, keys_np, dev):
+    n = keys_np.size
+    dk, alt = to_dev(keys_np, dev), torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    seq = gs.rdxsrt_unstable_sort(dk, None, n, alt, None)
+    assert seq.sorted_keys is dk, "32-bit keys: result must be in the caller's input array (gpu_radix_sort.h:359-360)"
+    assert seq.sorted_values is None
+    return to_u32(seq.sorted_keys)[:n]
+
+
+def _msb_pairs(gs, keys_np, vals_np, dev):
+    n = keys_np.size
+    dk, dv = to_dev(keys_np, dev), to_dev(vals_np, dev)
+    ka, va = torch.empty(max(n, 1), dtype=torch.int32, device=dev), torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    seq = gs.rdxsrt_unstable_sort(dk, dv, n, ka, va)
+    assert seq.sorted_keys is dk and seq.sorted_values is dv
+    return to_u32(seq.sorted_keys)[:n], to_u32(seq.sorted_values)[:n]
+
+
+@pytest.mark.parametrize("level", ENTROPY_LEVELS)
+def test_sort_keys_entropy_uint(gs, cuda, oracle, level):
+    n = 200000                                     # sort_keys_default_prob_size (msb/tests/main.cu:41)
+    keys = oracle.gen_entropy_and(n, level, seed=0)
+    got = _msb_keys(gs, keys, cuda)
+    assert oracle.msb_check_keys(keys, got) == 0
+
+
+@pytest.mark.parametrize("level", ENTROPY_LEVELS)
+def test_sort_pairs_entropy_uint_uint(gs, cuda, oracle, level):
+    n = 100000                                     # sort_pairs_default_prob_size
+    keys = oracle.gen_entropy_and(n, level, seed=0)
+    # (a) fast check: enumerated values
+    vals = oracle.gen_enumerated(n)
+    ks, vs = _msb_pairs(gs, keys, vals, cuda)
+    assert oracle.msb_check_pairs_enumerated(keys, ks, vs) == 0
+    # (b) full check: random values, secondary sort inside equal-key runs
+    vals = oracle.gen_uniform(n, seed=99)
+    ks, vs = _msb_pairs(gs, keys, vals, cuda)
+    assert oracle.msb_check_pairs(keys, vals, ks, vs) == 0
+
+
+def _numkeys_sweep(nmax):
+    out, x = [], 100000.0
+    while x < nmax:
+        out.append(int(x))
+        x *= 10 ** 0.1                              # test_sort_keys.cu:179
+    return out + [nmax]
+
+
+def test_sort_keys_numkeys_sweep(gs, cuda, oracle):
+    for n in _numkeys_sweep(1500000):
+        for level in (1, 4, 0):
+            keys = oracle.gen_entropy_and(n, level, seed=0)
+            assert np.array_equal(_msb_keys(gs, keys, cuda), np.sort(keys)), (n, level)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4608, 4609, 6911, 6912, 6913,
+                               9216, 9217, 17408, 17409, 65539, (1 << 20) + 7, (1 << 24) + 1])
+def test_sizes_keys_and_pairs(gs, cuda, oracle, n):
+    keys = oracle.gen_uniform(n, seed=n)
+    assert np.array_equal(_msb_keys(gs, keys, cuda), np.sort(keys))
+    vals = oracle.gen_enumerated(n)
+    ks, vs = _msb_pairs(gs, keys, vals, cuda)
+    assert oracle.msb_check_pairs_enumerated(keys, ks, vs) == 0
+
+
+@pytest.mark.parametrize("kind", ["zipf", "few_values", "one_hot_bucket", "sorted", "reverse", "top_byte_const"])
+def test_skewed_inputs(gs, cuda, oracle, kind):
+    n = 3000017
+    if kind == "zipf":
+        keys = oracle.gen_zipf(n)
+    elif kind == "few_values":
+        keys = (oracle.gen_uniform(n, seed=3) % 5) * np.uint32(0x01010101)
+    elif kind == "one_hot_bucket":               # 90 % identical keys, rest uniform
+        keys = oracle.gen_uniform(n, seed=4)
+        keys[oracle.gen_uniform(n, seed=5) % 10 != 0] = 0xDEADBEEF
+    elif kind == "sorted":
+        keys = np.sort(oracle.gen_uniform(n, seed=6))
+    elif kind == "reverse":
+        keys = np.sort(oracle.gen_uniform(n, seed=7))[::-1].copy()
+    else:                                        # everything in one top-byte bucket
+        keys = (oracle.gen_uniform(n, seed=8) & 0x00FFFFFF) | 0x5A000000
+    assert np.array_equal(_msb_keys(gs, keys, cuda), np.sort(keys))
+    vals = oracle.gen_enumerated(n)
+    ks, vs = _msb_pairs(gs, keys, vals, cuda)
+    assert oracle.msb_check_pairs_enumerated(keys, ks, vs) == 0
+
+
+def test_signed_and_float_keys(gs, cuda, oracle):
+    n = 500003
+    raw = oracle.gen_uniform(n, seed=21)
+    dk, alt = to_dev(raw, cuda), torch.empty(n, dtype=torch.int32, device=cuda)
+    seq = gs.rdxsrt_unstable_sort(dk, None, n, alt, None, key_type=gs.GS_KEY_I32)
+    assert np.array_equal(to_u32(seq.sorted_keys).view(np.int32), np.sort(raw.view(np.int32)))
+    f = raw.view(np.float32).copy()
+    f[np.isnan(f)] = 2.5
+    dk = to_dev(f.view(np.uint32), cuda)
+    seq = gs.rdxsrt_unstable_sort(dk, None, n, alt, None, key_type=gs.GS_KEY_F32)
+    got = to_u32(seq.sorted_keys).view(np.float32)
+    assert np.all(got[1:] >= got[:-1]) and np.array_equal(np.sort(got.view(np.uint32)), np.sort(f.view(np.uint32)))
+
+
+def test_host_pointer_wrappers(gs, cuda, oracle):
+    """rdxsrt_unstable_sort_keys / _pairs (gpu_radix_sort.h:511-587): host arrays in and out."""
+    n = 123457
+    keys = oracle.gen_entropy_and(n, 2, seed=1)
+    assert np.array_equal(gs.rdxsrt_unstable_sort_keys(keys), np.sort(keys))
+    vals = oracle.gen_enumerated(n)
+    ks, vs = gs.rdxsrt_unstable_sort_pairs(keys, vals)
+    assert oracle.msb_check_pairs_enumerated(keys, ks, vs) == 0
+
+
+def test_workspace_reuse_and_too_small(gs, cuda, oracle):
+    n = 400000
+    need = gs.lib.gs_msb_temp_bytes(n, 0)
+    dm = torch.empty(need, dtype=torch.uint8, device=cuda)
+    for seed in (1, 2, 3):                          # pre-allocated data manager reused across calls
+        keys = oracle.gen_uniform(n, seed=seed)
+        dk, alt = to_dev(keys, cuda), torch.empty(n, dtype=torch.int32, device=cuda)
+        seq = gs.rdxsrt_unstable_sort(dk, None, n, alt, None, pre_allocated_dm=dm)
+        assert np.array_equal(to_u32(seq.sorted_keys), np.sort(keys))
+    with pytest.raises(gs.GpuSortError):
+        gs.rdxsrt_unstable_sort(dk, None, n, alt, None, pre_allocated_dm=dm[:1024])
+
+
+@pytest.mark.parametrize("dist", ["uniform", "zipf"])
+def test_large_properties(gs, cuda, dist):
+    """2^27 keys (+ enumerated values): device-side sortedness, multiset checksum, value->key map."""
+    n = 1 << 27
+    gen = gs.generate_uniform_keys if dist == "uniform" else gs.generate_zipf_keys
+    keys = gen(n, seed=0, device=cuda)
+    orig = keys.clone()
+    _, s0, x0 = gs.check_sorted(keys)
+    vals = gs.generate_enumerated_values(n, device=cuda)
+    seq = gs.rdxsrt_unstable_sort(keys, vals, n, torch.empty_like(keys), torch.empty_like(keys))
+    inv, s1, x1 = gs.check_sorted(seq.sorted_keys)
+    assert inv == 0 and (s1, x1) == (s0, x0)
+    bad, vsum = gs.check_pairs_enumerated(orig, seq.sorted_keys, seq.sorted_values)
+    assert bad == 0 and vsum == n * (n - 1) // 2
