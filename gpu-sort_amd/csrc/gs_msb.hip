@@ -172,6 +172,8 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t s_cnt[RADIX], s_abs[RADIX], s_task[RADIX], s_nsub[RADIX];
     __shared__ uint8_t s_large[RADIX];
+    __shared__ uint32_t s_tot[2], s_ccnt[MSB_NCLASS], s_cbase[MSB_NCLASS];
+    __shared__ unsigned long long s_base64;
     const uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
     const int d = threadIdx.x;
     const uint32_t cap_max = msb_class_cap(nclass - 1);
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
         if (L > 0) row[d] = abs;
         if (LAST) continue;
         s_cnt[d] = c; s_abs[d] = abs; s_task[d] = 0; s_nsub[d] = 0; s_large[d] = 0;
+        if (d < MSB_NCLASS) s_ccnt[d] = 0;
         __syncthreads();
         if (d == 0) {
             int run_start = -1;
@@ -207,18 +210,35 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
             if (run_start >= 0) { s_task[run_start] = run_sum; s_nsub[run_start] = run_nsub; }
         }
         __syncthreads();
+        // one global atomic per block and list (not per entry): count the block's new
+        // buckets / tiles and its tasks per class in LDS, reserve the ranges, then fill
         uint32_t new_bucket = 0xffffffffu;
-        if (s_large[d]) {
-            const uint32_t tiles = (c + MSB_TILE - 1) / MSB_TILE;
-            const unsigned long long old = atomicAdd(&ws.level[L + 1].packed, (1ull << 32) | tiles);
-            new_bucket = (uint32_t)(old >> 32);
-            ws.buckets[(L + 1) & 1][new_bucket] = MsbBucket{abs, c, (uint32_t)old, 0u};
-        } else if (s_task[d]) {
-            const uint32_t size = s_task[d];
-            int cls = 0;
-            while (msb_class_cap(cls) < size) ++cls;
-            const uint32_t ti = atomicAdd(&ws.level[L].task_count[cls], 1u);
-            ws.tasks[cls][ti] = MsbTask{abs, size, rb + (s_nsub[d] > 1 ? 8u : 0u), 0u};
+        const bool is_large = s_large[d] != 0;
+        const uint32_t tsize = s_task[d];
+        int cls = 0;
+        if (tsize) while (msb_class_cap(cls) < tsize) ++cls;
+        const uint32_t tiles = is_large ? (c + MSB_TILE - 1) / MSB_TILE : 0u;
+        // exclusive prefixes inside the block (bucket index, tile index) keep tile_start sorted
+        const uint32_t bidx = block_exclusive_scan_256(is_large ? 1u : 0u, scratch, &s_tot[0]);
+        const uint32_t tidx = block_exclusive_scan_256(tiles, scratch, &s_tot[1]);
+        uint32_t task_local = 0;
+        if (tsize) task_local = atomicAdd(&s_ccnt[cls], 1u);          // LDS
+        __syncthreads();
+        if (d == 0) {
+            unsigned long long old = 0;
+            if (s_tot[0]) old = atomicAdd(&ws.level[L + 1].packed, ((unsigned long long)s_tot[0] << 32) | s_tot[1]);
+            s_base64 = old;
+        }
+        if (d < MSB_NCLASS) {
+            const uint32_t k = s_ccnt[d];
+            s_cbase[d] = k ? atomicAdd(&ws.level[L].task_count[d], k) : 0u;
+        }
+        __syncthreads();
+        if (is_large) {
+            new_bucket = (uint32_t)(s_base64 >> 32) + bidx;
+            ws.buckets[(L + 1) & 1][new_bucket] = MsbBucket{abs, c, (uint32_t)s_base64 + tidx, 0u};
+        } else if (tsize) {
+            ws.tasks[cls][s_cbase[cls] + task_local] = MsbTask{abs, tsize, rb + (s_nsub[d] > 1 ? 8u : 0u), 0u};
         }
         // clear the histogram rows of the buckets just created (all threads help)
         s_cnt[d] = new_bucket;
