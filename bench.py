@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=27)
     ap.add_argument("--verify", action="store_true", help="device-side sortedness + checksum on every step")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the bucket-sharded pipeline even on one rank (exercises the N>1 code path)")
     return ap.parse_args()
 
 
@@ -109,9 +111,10 @@ def main():
         vals = [gs.generate_enumerated_values(n, device=dev) for _ in range(total)]
         vals_alt = torch.empty(n, dtype=torch.int32, device=dev)
 
-    if world > 1:
+    sharded_path = world > 1 or args.force_sharded
+    if sharded_path:
         from gpu_sort_amd import sharded
-        runner = sharded.ShardedSorter(n, args.pairs, dev)
+        runner = sharded.ShardedSorter(n, args.pairs, dev, local_algo=args.algo or "lsb")
         nbytes = 0
         temp = None
     elif algo == "lsb":
@@ -124,10 +127,10 @@ def main():
     checks = []
 
     def one_step(i):
-        if world > 1:
-            out = runner.sort(inputs[i], vals[i] if args.pairs else None)
+        if sharded_path:
+            sk, sv, cnt = runner.sort(inputs[i], vals[i] if args.pairs else None)
             if args.verify:
-                checks.append(runner.verify(out))
+                checks.append(runner.verify(sk, cnt, pre[i])[0])
             return
         if algo == "lsb":
             dk = gs.DoubleBuffer(inputs[i], alt)
@@ -150,8 +153,10 @@ def main():
         torch.cuda.synchronize()
 
     pre = None
-    if args.verify and world == 1:
+    if args.verify and not sharded_path:
         pre = [gs.check_sorted(inputs[i])[1:] for i in range(total)]
+    elif args.verify:
+        pre = [runner.input_checksum(inputs[i]) for i in range(total)]
 
     for i in range(warmup):
         one_step(i)
@@ -171,7 +176,7 @@ def main():
         elapsed = float(t.item())
 
     verified = None
-    if args.verify and world == 1:
+    if args.verify and not sharded_path:
         verified = True
         for j, res in enumerate(checks):
             inv, s, x = gs.check_sorted(res)
@@ -183,11 +188,12 @@ def main():
         keys_total = n * world * steps
         value = keys_total / elapsed / 1e9
         ms_per_step = elapsed / steps * 1e3
-        dom = "lsb_downsweep" if algo == "lsb" and world == 1 else ("msb_partition" if "msb_partition" in kernels else None)
+        dom = "lsb_downsweep" if "lsb_downsweep" in kernels else ("msb_partition" if "msb_partition" in kernels else None)
         roofline = None
         if dom and dom in kernels:
             ms, cnt = kernels[dom]
             avg_ms = ms / cnt
+            # keys per launch: the whole array on one GPU; a rank's received slice (~n) when sharded
             alg_bytes = DOWNSWEEP_BYTES_PER_KEY[args.pairs] * n
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
             pmc = load_pmc_traffic()
@@ -213,9 +219,9 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": (f"{algo}_radix_sort_2^{args.log2n}_u32_{args.dist}_"
-                                    f"{'pairs' if args.pairs else 'keys_only'}" + ("_per_gpu_sharded" if world > 1 else "")),
+                                    f"{'pairs' if args.pairs else 'keys_only'}" + ("_per_gpu_sharded" if sharded_path else "")),
                        "keys_per_gpu": n, "has_values": args.pairs, "algorithm": algo,
-                       "distribution": args.dist, "parallelism": "single" if world == 1 else f"msb_bucket_shard{world}"},
+                       "distribution": args.dist, "parallelism": "single" if not sharded_path else f"msb_bucket_shard{world}"},
             "roofline": roofline, "whole_sort": whole, "cpu_baseline": cpu,
             "kernels_ms_total": {k: [round(v[0], 3), v[1]] for k, v in kernels.items()},
         }

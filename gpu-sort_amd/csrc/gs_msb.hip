@@ -126,7 +126,22 @@ __device__ __forceinline__ uint32_t msb_find_bucket(const MsbBucket *__restrict_
 // -------------------------------------------------------------- histogram --
 // M3: 256-bin histogram of byte `shift/8` for every tile of every bucket of level L,
 // accumulated per bucket with one global atomic per non-empty bin and tile.
-__global__ __launch_bounds__(MSB_THREADS) void msb_hist_kernel(MsbWs ws, int L, const uint32_t *__restrict__ src, int shift)
+// digit of a key: byte `shift/8`, or -- multi-GPU sharding -- the destination rank looked up
+// from the key's top bits: remap[twiddle_in(key) >> rshift]
+struct DigitSel {
+    int shift;                  // used when remap == nullptr
+    const uint8_t *remap;       // destination of each top-bits bin, or nullptr
+    int rshift;
+    int f32_in;
+    uint32_t xor_in;
+};
+__device__ __forceinline__ uint32_t digit_of(const DigitSel &ds, uint32_t k)
+{
+    if (ds.remap) return ds.remap[twiddle_in(k, ds.f32_in, ds.xor_in) >> ds.rshift];
+    return (k >> ds.shift) & 255u;
+}
+
+__global__ __launch_bounds__(MSB_THREADS) void msb_hist_kernel(MsbWs ws, int L, const uint32_t *__restrict__ src, DigitSel ds)
 {
     __shared__ uint32_t lh[MSB_WAVES][RADIX];
     const unsigned long long packed = ws.level[L].packed;
@@ -144,7 +159,7 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_hist_kernel(MsbWs ws, int L, 
         for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
         const uint32_t *p = src + lo;
         for (uint32_t i = (uint32_t)w * WAVE + lane; i < len; i += MSB_THREADS)
-            atomicAdd(&my[(p[i] >> shift) & 255u], 1u);
+            atomicAdd(&my[digit_of(ds, p[i])], 1u);
         __syncthreads();
         if (tid < RADIX) {
             uint32_t s = 0;
@@ -165,7 +180,8 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_hist_kernel(MsbWs ws, int L, 
 //                                 greedily while the running sum is < MSB_MERGE and
 //                                 still fits (a merged task also re-sorts this byte).
 // LAST (byte 0): only the cursors are needed, the scatter finishes everything.
-// `counts0`: level 0 reads the LSB pass's digit totals instead of hist[0].
+// `counts0`: level 0 of the sort reads the LSB pass's digit totals instead of a histogram row
+// (and needs no cursors: the LSB downsweep does that scatter).
 template <bool LAST>
 __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, const uint32_t *__restrict__ counts0, int nclass)
 {
@@ -181,10 +197,10 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const MsbBucket B = ws.buckets[L & 1][b];
         uint32_t *row = ws.hist[L & 1] + (size_t)b * RADIX;
-        const uint32_t c = (L == 0) ? counts0[d] : row[d];
+        const uint32_t c = counts0 ? counts0[d] : row[d];
         const uint32_t ex = block_exclusive_scan_256(c, scratch, nullptr);
         const uint32_t abs = B.offset + ex;
-        if (L > 0) row[d] = abs;
+        if (!counts0) row[d] = abs;
         if (LAST) continue;
         s_cnt[d] = c; s_abs[d] = abs; s_task[d] = 0; s_nsub[d] = 0; s_large[d] = 0;
         if (d < MSB_NCLASS) s_ccnt[d] = 0;
@@ -262,7 +278,7 @@ template <bool HAS_VALUES>
 __global__ __launch_bounds__(MSB_THREADS, 4) void msb_scatter_kernel(MsbWs ws, int L, const uint32_t *__restrict__ src_k,
                                                                     uint32_t *__restrict__ dst_k,
                                                                     const uint32_t *__restrict__ src_v,
-                                                                    uint32_t *__restrict__ dst_v, int shift, int f32_out,
+                                                                    uint32_t *__restrict__ dst_v, DigitSel ds, int f32_out,
                                                                     uint32_t xor_out)
 {
     __shared__ uint32_t scratch[8];
@@ -292,7 +308,7 @@ __global__ __launch_bounds__(MSB_THREADS, 4) void msb_scatter_kernel(MsbWs ws, i
     for (int i = 0; i < MSB_KPT; ++i) {
         const uint32_t idx = (uint32_t)tid + i * MSB_THREADS;
         const bool ok = idx < valid;
-        const uint32_t d = (key[i] >> shift) & 255u;
+        const uint32_t d = digit_of(ds, key[i]);
         const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
         if (__builtin_amdgcn_ballot_w64(ok && d == d0) == ~0ull) {
             // whole wave on one digit: one atomic for 64 keys
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(MSB_THREADS, 4) void msb_scatter_kernel(MsbWs ws, i
     for (int i = 0; i < MSB_KPT; ++i) {
         const uint32_t idx = (uint32_t)tid + i * MSB_THREADS;
         if (idx < valid) {
-            const uint32_t at = lex[(key[i] >> shift) & 255u] + rnk[i];
+            const uint32_t at = lex[digit_of(ds, key[i])] + rnk[i];
             if (HAS_VALUES) reinterpret_cast<uint2 *>(stage)[at] = make_uint2(key[i], val[i]);
             else stage[at] = key[i];
         }
@@ -335,7 +351,7 @@ __global__ __launch_bounds__(MSB_THREADS, 4) void msb_scatter_kernel(MsbWs ws, i
             } else {
                 k = stage[slot];
             }
-            const uint32_t dst = gbase[(k >> shift) & 255u] + slot;
+            const uint32_t dst = gbase[digit_of(ds, k)] + slot;
             dst_k[dst] = twiddle_out(k, f32_out, xor_out);
             if (HAS_VALUES) dst_v[dst] = v;
         }
@@ -453,6 +469,32 @@ __global__ __launch_bounds__(MSB_THREADS, 4) void msb_local_sort_kernel(MsbWs ws
     }
 }
 
+// ------------------------------------------------------------------ shard --
+constexpr int SHARD_MAX_BITS = 12;   // 4096 bins of the key space: 16 KiB of LDS counters
+
+// 2^bits-bin histogram of the keys' top bits (after the order-preserving twiddle), u64 counts
+__global__ __launch_bounds__(MSB_THREADS) void shard_hist_kernel(const uint32_t *__restrict__ keys, uint64_t n, int bits,
+                                                                 unsigned long long *__restrict__ hist, int f32_in,
+                                                                 uint32_t xor_in)
+{
+    __shared__ uint32_t lh[1 << SHARD_MAX_BITS];
+    const uint32_t nb = 1u << bits;
+    for (uint32_t i = threadIdx.x; i < nb; i += MSB_THREADS) lh[i] = 0;
+    __syncthreads();
+    const int rshift = 32 - bits;
+    // a block never counts more than 2^32 keys (n < 2^32 per call site), so u32 LDS counters suffice
+    for (uint64_t i = (uint64_t)blockIdx.x * MSB_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * MSB_THREADS)
+        atomicAdd(&lh[twiddle_in(keys[i], f32_in, xor_in) >> rshift], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb; i += MSB_THREADS)
+        if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+}
+
+__global__ void shard_counts_kernel(const uint32_t *__restrict__ row, int num_ranks, unsigned long long *__restrict__ counts)
+{
+    if ((int)threadIdx.x < num_ranks) counts[threadIdx.x] = row[threadIdx.x];
+}
+
 // ------------------------------------------------------------------- host --
 
 template <bool HAS_VALUES>
@@ -537,6 +579,7 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
 
         for (int L = 1; L <= 3; ++L) {
             const int shift = 24 - 8 * L;
+            const DigitSel dsel{shift, nullptr, 0, 0, 0u};
             uint32_t *sk = buf_k[L & 1], *dk = buf_k[(L + 1) & 1];
             uint32_t *sv = buf_v[L & 1], *dv = buf_v[(L + 1) & 1];
             // buckets at level L: <= 256 at level 1, else bounded by size; tiles: n/T + one ragged tile per bucket
@@ -545,7 +588,7 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
             const uint32_t max_tiles = max_tiles_ub < MSB_MAX_GRID ? max_tiles_ub : MSB_MAX_GRID;
             const bool last = (L == 3);
             { KernelTimer kt(GS_K_MSB_HISTOGRAM, s);
-              hipLaunchKernelGGL(msb_hist_kernel, dim3(max_tiles), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, shift); }
+              hipLaunchKernelGGL(msb_hist_kernel, dim3(max_tiles), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, dsel); }
             { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
               const uint32_t cg = max_b < 4096u ? max_b : 4096u;
               if (last) hipLaunchKernelGGL(msb_classify_kernel<true>, dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass);
@@ -553,10 +596,10 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
             { KernelTimer kt(GS_K_MSB_PARTITION, s);
               if (pairs)
                   hipLaunchKernelGGL(msb_scatter_kernel<true>, dim3(max_tiles), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, dk,
-                                     (const uint32_t *)sv, dv, shift, last ? tw.f32_out : 0, last ? tw.xor_out : 0u);
+                                     (const uint32_t *)sv, dv, dsel, last ? tw.f32_out : 0, last ? tw.xor_out : 0u);
               else
                   hipLaunchKernelGGL(msb_scatter_kernel<false>, dim3(max_tiles), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, dk,
-                                     (const uint32_t *)nullptr, (uint32_t *)nullptr, shift, last ? tw.f32_out : 0, last ? tw.xor_out : 0u); }
+                                     (const uint32_t *)nullptr, (uint32_t *)nullptr, dsel, last ? tw.f32_out : 0, last ? tw.xor_out : 0u); }
             if (!last) {
                 if (pairs) launch_local_sorts<true>(ws, L, max_tasks_lvl, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s);
                 else launch_local_sorts<false>(ws, L, max_tasks_lvl, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s);
@@ -569,8 +612,63 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
     return err;
 }
 
-int gs_shard_histogram_u32(const uint32_t *, uint64_t, int, uint64_t *, int, void *) { return hipErrorNotSupported; }
-int gs_shard_partition_u32(void *, size_t, const uint32_t *, uint32_t *, const uint32_t *, uint32_t *, uint64_t, int,
-                           const uint8_t *, int, uint64_t *, int, void *) { return hipErrorNotSupported; }
+int gs_shard_histogram_u32(const uint32_t *d_keys, uint64_t num_items, int bits, uint64_t *d_hist, int key_type,
+                           void *stream)
+{
+    if (bits < 1 || bits > SHARD_MAX_BITS || !d_hist) return hipErrorInvalidValue;
+    if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d_hist, 0, sizeof(uint64_t) << bits, s);
+    if (e != hipSuccess) return (int)e;
+    if (num_items == 0) return hipSuccess;
+    if (!d_keys) return hipErrorInvalidValue;
+    PassParams tw{};
+    lsb_twiddle_masks(key_type, 0, true, true, tw);
+    const uint64_t blocks = (num_items + MSB_TILE - 1) / MSB_TILE;
+    KernelTimer kt(GS_K_SHARD, s);
+    hipLaunchKernelGGL(shard_hist_kernel, dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(MSB_THREADS), 0, s, d_keys,
+                       num_items, bits, (unsigned long long *)d_hist, tw.f32_in, tw.xor_in);
+    return (int)hipGetLastError();
+}
+
+int gs_shard_partition_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys_in, uint32_t *d_keys_out,
+                           const uint32_t *d_vals_in, uint32_t *d_vals_out, uint64_t num_items, int bits,
+                           const uint8_t *d_dest_of_bin, int num_ranks, uint64_t *d_counts, int key_type, void *stream)
+{
+    if (bits < 1 || bits > SHARD_MAX_BITS || num_ranks < 1 || num_ranks > RADIX || !d_dest_of_bin || !d_counts)
+        return hipErrorInvalidValue;
+    if (num_items >= (1ull << 32)) return hipErrorInvalidValue;
+    if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e0 = hipMemsetAsync(d_counts, 0, sizeof(uint64_t) * num_ranks, s);
+    if (e0 != hipSuccess) return (int)e0;
+    if (num_items == 0) return hipSuccess;
+    if ((d_vals_in == nullptr) != (d_vals_out == nullptr) || !d_keys_in || !d_keys_out) return hipErrorInvalidValue;
+    const bool pairs = d_vals_in != nullptr;
+    if (!d_temp || temp_bytes < gs_msb_temp_bytes(num_items, pairs)) return hipErrorInvalidValue;
+    const uint32_t n = (uint32_t)num_items;
+    const MsbWs ws = msb_carve((char *)d_temp + align256(lsb_temp_bytes(num_items)), num_items, pairs);
+    PassParams tw{};
+    lsb_twiddle_masks(key_type, 0, true, true, tw);
+    const DigitSel dsel{0, d_dest_of_bin, 32 - bits, tw.f32_in, tw.xor_in};
+    const uint32_t tiles = (n + MSB_TILE - 1) / MSB_TILE;
+    const uint32_t grid = tiles < MSB_MAX_GRID ? tiles : MSB_MAX_GRID;
+    KernelTimer kt(GS_K_SHARD, s);
+    // one bucket = the whole shard, "digit" = destination rank: histogram, cursors, unstable scatter
+    hipLaunchKernelGGL(msb_init_kernel, dim3(1), dim3(64), 0, s, ws, n);
+    hipMemsetAsync(ws.hist[0], 0, RADIX * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(msb_hist_kernel, dim3(grid), dim3(MSB_THREADS), 0, s, ws, 0, d_keys_in, dsel);
+    hipLaunchKernelGGL(shard_counts_kernel, dim3(1), dim3(RADIX), 0, s, (const uint32_t *)ws.hist[0], num_ranks,
+                       (unsigned long long *)d_counts);
+    hipLaunchKernelGGL(msb_classify_kernel<true>, dim3(1), dim3(256), 0, s, ws, 0 /* cursors only */,
+                       (const uint32_t *)nullptr, 0);
+    if (pairs)
+        hipLaunchKernelGGL(msb_scatter_kernel<true>, dim3(grid), dim3(MSB_THREADS), 0, s, ws, 0, d_keys_in, d_keys_out, d_vals_in,
+                           d_vals_out, dsel, 0, 0u);
+    else
+        hipLaunchKernelGGL(msb_scatter_kernel<false>, dim3(grid), dim3(MSB_THREADS), 0, s, ws, 0, d_keys_in, d_keys_out,
+                           (const uint32_t *)nullptr, (uint32_t *)nullptr, dsel, 0, 0u);
+    return (int)hipGetLastError();
+}
 
 }  // extern "C"

@@ -1,0 +1,195 @@
+"""Multi-GPU bucket-sharded sort: one process per GPU, ONE all-to-all (RCCL over xGMI).
+
+The reference is single-GPU; this is the north_star's 8-GPU path:
+  1. every rank histograms the top SHARD_BITS bits of its shard        (gs_shard_histogram_u32)
+  2. all ranks exchange the histograms (all_gather, 32 KiB)            (torch.distributed)
+  3. every rank computes the same monotone bin -> rank map with balanced totals
+  4. every rank groups its keys (and values) by destination rank        (gs_shard_partition_u32)
+  5. one all_to_all_single with uneven splits moves every key to its owner
+  6. every rank sorts what it received                                  (gs_lsb_sort_u32 / gs_msb_sort_u32)
+Rank r then holds the r-th slice of the globally sorted sequence.
+
+The compute steps go through `ops` (DeviceOps = the HIP library).  The host logic --
+split computation and exchange plan -- is backend-independent, so the CPU test-suite
+drives it over gloo with a numpy stand-in for `ops` (tests/test_sharded_cpu.py).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+SHARD_BITS = 12
+
+
+def compute_splits(hist_all, world):
+    """hist_all: (world, nbins) counts.  Returns (dest_of_bin uint8[nbins], recv_total per rank).
+
+    Bins are assigned to ranks in key order; bin b goes to rank floor(G * keys_before_b / N),
+    so every rank owns a contiguous key range and totals are balanced to within one bin."""
+    tot = hist_all.sum(axis=0).astype(np.uint64)
+    n = int(tot.sum())
+    before = np.cumsum(tot, dtype=np.uint64) - tot
+    if n == 0:
+        dest = np.zeros(tot.size, np.uint8)
+    else:
+        dest = np.minimum((before.astype(np.float64) * world / n).astype(np.int64), world - 1).astype(np.uint8)
+        dest = np.maximum.accumulate(dest)          # monotone by construction; keep it so under rounding
+    per_rank = np.array([int(tot[dest == r].sum()) for r in range(world)], dtype=np.int64)
+    return dest, per_rank
+
+
+def exchange_plan(hist_all, dest, rank, world):
+    """send_counts[r] = my keys going to rank r; recv_counts[r] = keys rank r sends to me."""
+    send = np.array([int(hist_all[rank][dest == r].sum()) for r in range(world)], dtype=np.int64)
+    recv = np.array([int(hist_all[r][dest == rank].sum()) for r in range(world)], dtype=np.int64)
+    return send, recv
+
+
+class DeviceOps:
+    """Compute steps on the GPU through the C ABI (libgpusort.so)."""
+
+    def __init__(self, device):
+        from . import _lib
+        from .lsb import _stream_ptr
+        self.lib, self.check, self._lib, self._sp = _lib.lib, _lib.check, _lib, _stream_ptr
+        self.device = device
+
+    def histogram(self, keys, n, bits):
+        hist = torch.empty(1 << bits, dtype=torch.int64, device=self.device)
+        self.check(self.lib.gs_shard_histogram_u32(keys.data_ptr(), n, bits, hist.data_ptr(), self._lib.GS_KEY_U32,
+                                                   self._sp(None)), "gs_shard_histogram_u32")
+        return hist
+
+    def partition(self, keys, vals, n, bits, dest_np, world, temp, keys_out, vals_out):
+        dest = torch.from_numpy(dest_np).to(self.device)
+        counts = torch.empty(world, dtype=torch.int64, device=self.device)
+        self.check(self.lib.gs_shard_partition_u32(temp.data_ptr(), temp.numel(), keys.data_ptr(), keys_out.data_ptr(),
+                                                   vals.data_ptr() if vals is not None else None,
+                                                   vals_out.data_ptr() if vals is not None else None, n, bits,
+                                                   dest.data_ptr(), world, counts.data_ptr(), self._lib.GS_KEY_U32,
+                                                   self._sp(None)), "gs_shard_partition_u32")
+        return counts
+
+    def temp_bytes(self, n, pairs):
+        return max(self.lib.gs_msb_temp_bytes(n, int(pairs)), self.lib.gs_lsb_temp_bytes(n, int(pairs)), 256)
+
+    def local_sort(self, keys, vals, n, keys_alt, vals_alt, temp, algo="lsb"):
+        from . import DoubleBuffer, DeviceRadixSort, rdxsrt_unstable_sort, GS_KEY_U32
+        if n == 0:
+            return keys, vals
+        if algo == "msb":
+            seq = rdxsrt_unstable_sort(keys, vals, n, keys_alt, vals_alt, pre_allocated_dm=temp, synchronize=False)
+            return seq.sorted_keys, seq.sorted_values
+        dk = DoubleBuffer(keys, keys_alt)
+        if vals is not None:
+            dv = DoubleBuffer(vals, vals_alt)
+            DeviceRadixSort.SortPairs(temp, temp.numel(), dk, dv, n, key_type=GS_KEY_U32)
+            return dk.Current(), dv.Current()
+        DeviceRadixSort.SortKeys(temp, temp.numel(), dk, n, key_type=GS_KEY_U32)
+        return dk.Current(), None
+
+    def empty(self, n):
+        return torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+
+    def check_sorted(self, keys, count):
+        from . import check_sorted
+        return check_sorted(keys, count) if count else (0, 0, 0)
+
+
+class ShardedSorter:
+    """Sorts a key array that is sharded over the ranks of the default process group."""
+
+    def __init__(self, keys_per_rank, pairs, device, ops=None, local_algo="lsb", slack=1.25, group=None):
+        self.n, self.pairs, self.device, self.group = keys_per_rank, pairs, device, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.ops = ops if ops is not None else DeviceOps(device)
+        self.local_algo = local_algo
+        # receive capacity: balanced splits give ~n per rank; `slack` covers coarse bins / skew.
+        # A heavier rank (one key value owning more than a bin can split) grows the buffers on demand.
+        self.cap = int(keys_per_rank * slack) + 4096
+        self._alloc(self.cap)
+        self.part_k = self.ops.empty(self.n)
+        self.part_v = self.ops.empty(self.n) if pairs else None
+        self.last = None
+
+    def _alloc(self, cap):
+        self.cap = cap
+        self.recv_k, self.alt_k = self.ops.empty(cap), self.ops.empty(cap)
+        self.recv_v = self.ops.empty(cap) if self.pairs else None
+        self.alt_v = self.ops.empty(cap) if self.pairs else None
+        self.temp = torch.empty(self.ops.temp_bytes(max(cap, self.n), self.pairs), dtype=torch.uint8, device=self.device)
+
+    def sort(self, keys, vals=None):
+        """keys (and vals): this rank's shard (device tensors of self.n elements).
+        Returns (sorted_keys, sorted_vals, count): this rank's slice of the global order."""
+        n, world, rank = self.n, self.world, self.rank
+        hist = self.ops.histogram(keys, n, SHARD_BITS)
+        if world > 1:
+            gathered = torch.empty(world * hist.numel(), dtype=hist.dtype, device=hist.device)
+            dist.all_gather_into_tensor(gathered, hist, group=self.group)
+            hist_all = gathered.cpu().numpy().reshape(world, -1)
+        else:
+            hist_all = hist.cpu().numpy().reshape(1, -1)
+        dest, per_rank = compute_splits(hist_all, world)
+        send, recv = exchange_plan(hist_all, dest, rank, world)
+        m = int(recv.sum())
+        if m > self.cap:
+            self._alloc(int(m * 1.1) + 4096)
+        self.ops.partition(keys, vals, n, SHARD_BITS, dest, world, self.temp, self.part_k, self.part_v)
+        if world > 1:
+            dist.all_to_all_single(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), group=self.group)
+            if self.pairs:
+                dist.all_to_all_single(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), group=self.group)
+            rk, rv = self.recv_k, self.recv_v
+        else:
+            rk, rv = self.part_k, self.part_v
+            if m > rk.numel():
+                raise RuntimeError("internal: single-rank receive exceeds shard size")
+        sk, sv = self.ops.local_sort(rk, rv, m, self.alt_k if world > 1 else self.recv_k,
+                                     self.alt_v if world > 1 else self.recv_v, self.temp, self.local_algo)
+        self.last = dict(count=m, send=send, recv=recv, per_rank=per_rank, dest=dest)
+        return sk, sv, m
+
+    def verify(self, sorted_keys, count, input_checksum=None):
+        """Global correctness from size-independent properties: every rank's slice is sorted, slices are
+        ordered across ranks, and the key multiset (count, sum and xor of a hash) is preserved."""
+        inv, s, x = self.ops.check_sorted(sorted_keys, count)
+        first = int(sorted_keys[0].item()) & 0xFFFFFFFF if count else None
+        last = int(sorted_keys[count - 1].item()) & 0xFFFFFFFF if count else None
+        info = [None] * self.world
+        mine = (inv, s, x, count, first, last)
+        if self.world > 1:
+            dist.all_gather_object(info, mine, group=self.group)
+        else:
+            info = [mine]
+        ok = all(i[0] == 0 for i in info)
+        prev_last = None
+        for i in info:
+            if i[3] == 0:
+                continue
+            if prev_last is not None and i[4] < prev_last:
+                ok = False
+            prev_last = i[5]
+        total = sum(i[3] for i in info)
+        ssum = sum(i[1] for i in info) % (1 << 64)
+        sxor = 0
+        for i in info:
+            sxor ^= i[2]
+        if input_checksum is not None:
+            ok = ok and (total, ssum, sxor) == input_checksum
+        return ok, (total, ssum, sxor)
+
+    def input_checksum(self, keys):
+        """(count, hash sum, hash xor) of the whole sharded input."""
+        _, s, x = self.ops.check_sorted(keys, self.n)
+        info = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(info, (s, x, self.n), group=self.group)
+        else:
+            info = [(s, x, self.n)]
+        sxor = 0
+        for i in info:
+            sxor ^= i[1]
+        return sum(i[2] for i in info), sum(i[0] for i in info) % (1 << 64), sxor
