@@ -1,0 +1,192 @@
+// gpusort.hpp -- header-only C++ shims over the C ABI (gpusort.h) that keep the call
+// shapes of the reference's two sort entry points, so lsb/sort.cu- and
+// msb/src/test.cu-shaped drivers compile against libgpusort.so with only the include
+// and the cuda* -> hip* runtime names changed.
+//
+//   gpusort::DoubleBuffer<T>                      <- cub::DoubleBuffer<T>      lsb/cub/cub/util_type.cuh:785-817
+//   gpusort::DeviceRadixSort::SortKeys/...        <- cub::DeviceRadixSort      lsb/cub/cub/device/device_radix_sort.cuh:248,595,754
+//   gpusort::NullType                             <- cub::NullType
+//   rdxsrt_unstable_sort<K,V,IndexT>(...)         <- msb/src/sort/gpu_radix_sort.h:197
+//   rdxsrt_unstable_sort_keys / _pairs            <- msb/src/sort/gpu_radix_sort.h:511,544
+//   RDXSRT_SortedSequence<K,V>                    <- msb/src/sort/gpu_radix_sort.h:31-34
+//
+// Supported key types: unsigned int, int, float (32-bit; the graded configurations are
+// u32); value type: any 4-byte trivially copyable type or NullType.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <type_traits>
+
+#include "gpusort.h"
+
+namespace gpusort {
+
+struct NullType {};
+
+template <typename T>
+struct DoubleBuffer {
+    T *d_buffers[2];
+    int selector;
+    DoubleBuffer() : d_buffers{nullptr, nullptr}, selector(0) {}
+    DoubleBuffer(T *d_current, T *d_alternate) : d_buffers{d_current, d_alternate}, selector(0) {}
+    T *Current() { return d_buffers[selector]; }
+    T *Alternate() { return d_buffers[selector ^ 1]; }
+};
+
+template <typename K> struct KeyTraits;
+template <> struct KeyTraits<unsigned int> { static constexpr int type = GS_KEY_U32; };
+template <> struct KeyTraits<int> { static constexpr int type = GS_KEY_I32; };
+template <> struct KeyTraits<float> { static constexpr int type = GS_KEY_F32; };
+
+struct DeviceRadixSort {
+    template <typename KeyT, typename ValueT>
+    static hipError_t Dispatch(void *d_temp_storage, size_t &temp_storage_bytes, DoubleBuffer<KeyT> &d_keys,
+                               DoubleBuffer<ValueT> *d_values, int num_items, int begin_bit, int end_bit,
+                               bool descending, hipStream_t stream)
+    {
+        static_assert(sizeof(KeyT) == 4, "32-bit keys only");
+        const size_t need = gs_lsb_temp_bytes((uint64_t)num_items, d_values != nullptr);
+        if (d_temp_storage == nullptr) {            // size query (dispatch_radix_sort.cuh:1110)
+            temp_storage_bytes = need;
+            return hipSuccess;
+        }
+        uint32_t *keys[2] = {reinterpret_cast<uint32_t *>(d_keys.d_buffers[0]),
+                             reinterpret_cast<uint32_t *>(d_keys.d_buffers[1])};
+        uint32_t *vals[2] = {nullptr, nullptr};
+        if (d_values) {
+            static_assert(std::is_same<ValueT, NullType>::value || sizeof(ValueT) == 4, "32-bit values only");
+            vals[0] = reinterpret_cast<uint32_t *>(d_values->d_buffers[0]);
+            vals[1] = reinterpret_cast<uint32_t *>(d_values->d_buffers[1]);
+        }
+        int sel = d_keys.selector;
+        const int err = gs_lsb_sort_u32(d_temp_storage, temp_storage_bytes, keys, d_values ? vals : nullptr, &sel,
+                                        (uint64_t)num_items, begin_bit, end_bit, descending ? 1 : 0,
+                                        KeyTraits<KeyT>::type, stream);
+        if (err == 0) {
+            d_keys.selector = sel;
+            if (d_values) d_values->selector = sel;
+        }
+        return static_cast<hipError_t>(err);
+    }
+
+    template <typename KeyT>
+    static hipError_t SortKeys(void *d_temp_storage, size_t &temp_storage_bytes, DoubleBuffer<KeyT> &d_keys,
+                               int num_items, int begin_bit = 0, int end_bit = sizeof(KeyT) * 8,
+                               hipStream_t stream = 0, bool /*debug_synchronous*/ = false)
+    {
+        return Dispatch<KeyT, NullType>(d_temp_storage, temp_storage_bytes, d_keys, nullptr, num_items, begin_bit,
+                                        end_bit, false, stream);
+    }
+    template <typename KeyT>
+    static hipError_t SortKeysDescending(void *d_temp_storage, size_t &temp_storage_bytes, DoubleBuffer<KeyT> &d_keys,
+                                         int num_items, int begin_bit = 0, int end_bit = sizeof(KeyT) * 8,
+                                         hipStream_t stream = 0, bool /*debug_synchronous*/ = false)
+    {
+        return Dispatch<KeyT, NullType>(d_temp_storage, temp_storage_bytes, d_keys, nullptr, num_items, begin_bit,
+                                        end_bit, true, stream);
+    }
+    template <typename KeyT, typename ValueT>
+    static hipError_t SortPairs(void *d_temp_storage, size_t &temp_storage_bytes, DoubleBuffer<KeyT> &d_keys,
+                                DoubleBuffer<ValueT> &d_values, int num_items, int begin_bit = 0,
+                                int end_bit = sizeof(KeyT) * 8, hipStream_t stream = 0,
+                                bool /*debug_synchronous*/ = false)
+    {
+        return Dispatch<KeyT, ValueT>(d_temp_storage, temp_storage_bytes, d_keys, &d_values, num_items, begin_bit,
+                                      end_bit, false, stream);
+    }
+    template <typename KeyT, typename ValueT>
+    static hipError_t SortPairsDescending(void *d_temp_storage, size_t &temp_storage_bytes, DoubleBuffer<KeyT> &d_keys,
+                                          DoubleBuffer<ValueT> &d_values, int num_items, int begin_bit = 0,
+                                          int end_bit = sizeof(KeyT) * 8, hipStream_t stream = 0,
+                                          bool /*debug_synchronous*/ = false)
+    {
+        return Dispatch<KeyT, ValueT>(d_temp_storage, temp_storage_bytes, d_keys, &d_values, num_items, begin_bit,
+                                      end_bit, true, stream);
+    }
+};
+
+}  // namespace gpusort
+
+// ---- MSB driver shims (global namespace, as in the reference) ---------------------
+
+template <typename KeyT, typename ValueT = gpusort::NullType>
+struct RDXSRT_SortedSequence {
+    KeyT *sorted_keys;
+    ValueT *sorted_values;
+};
+
+// Scratch owner standing in for RDXSRT_GPUDataManager (gpu_radix_sort.h:50-166): one
+// device allocation sized by gs_msb_temp_bytes instead of eight.
+struct RDXSRT_GPUDataManager {
+    void *d_temp = nullptr;
+    size_t bytes = 0;
+    RDXSRT_GPUDataManager(uint64_t key_count, bool has_values)
+    {
+        bytes = gs_msb_temp_bytes(key_count, has_values ? 1 : 0);
+        if (hipMalloc(&d_temp, bytes ? bytes : 1) != hipSuccess) { d_temp = nullptr; bytes = 0; }
+    }
+    ~RDXSRT_GPUDataManager() { if (d_temp) (void)hipFree(d_temp); }
+    RDXSRT_GPUDataManager(const RDXSRT_GPUDataManager &) = delete;
+    RDXSRT_GPUDataManager &operator=(const RDXSRT_GPUDataManager &) = delete;
+};
+
+// Ascending, unstable; synchronous like the reference (gpu_radix_sort.h:489-491); dev_values == NULL
+// (ValueT = NullType) sorts keys only (msb/src/test.cu:53).  Result pointers are returned and, for
+// 32-bit keys, are the caller's input arrays.
+template <typename KeyT, typename ValueT, typename IndexT = unsigned int>
+RDXSRT_SortedSequence<KeyT, ValueT> rdxsrt_unstable_sort(KeyT *dev_keys, ValueT *dev_values, IndexT key_count,
+                                                         KeyT *dev_sorted_keys_out, ValueT *dev_sorted_values_out,
+                                                         void * /*local_sort_configurations*/ = nullptr,
+                                                         RDXSRT_GPUDataManager *pre_allocated_dm = nullptr,
+                                                         hipStream_t stream = nullptr)
+{
+    static_assert(sizeof(KeyT) == 4, "32-bit keys only");
+    constexpr bool keys_only = std::is_same<ValueT, gpusort::NullType>::value;
+    const bool pairs = !keys_only && dev_values != nullptr;
+    RDXSRT_GPUDataManager *dm = pre_allocated_dm ? pre_allocated_dm : new RDXSRT_GPUDataManager((uint64_t)key_count, pairs);
+    uint32_t *sk = nullptr, *sv = nullptr;
+    (void)gs_msb_sort_u32(dm->d_temp, dm->bytes, reinterpret_cast<uint32_t *>(dev_keys),
+                          pairs ? reinterpret_cast<uint32_t *>(dev_values) : nullptr, (uint64_t)key_count,
+                          reinterpret_cast<uint32_t *>(dev_sorted_keys_out),
+                          pairs ? reinterpret_cast<uint32_t *>(dev_sorted_values_out) : nullptr, &sk, &sv,
+                          gpusort::KeyTraits<KeyT>::type, stream, 1);
+    if (!pre_allocated_dm) delete dm;
+    return RDXSRT_SortedSequence<KeyT, ValueT>{reinterpret_cast<KeyT *>(sk), reinterpret_cast<ValueT *>(sv)};
+}
+
+// Host-pointer conveniences (gpu_radix_sort.h:511-587): allocate, copy in, sort, copy the
+// result back from the INPUT device arrays, free.
+template <typename KeyT>
+void rdxsrt_unstable_sort_keys(KeyT *keys, const unsigned long long key_count, KeyT *sorted_keys_out)
+{
+    KeyT *dev_keys = nullptr, *dev_keys_out = nullptr;
+    const size_t bytes = sizeof(KeyT) * (key_count ? key_count : 1);
+    (void)hipMalloc(&dev_keys_out, bytes);
+    (void)hipMalloc(&dev_keys, bytes);
+    (void)hipMemcpy(dev_keys, keys, sizeof(KeyT) * key_count, hipMemcpyHostToDevice);
+    auto seq = rdxsrt_unstable_sort<KeyT, gpusort::NullType, unsigned int>(dev_keys, nullptr, (unsigned int)key_count,
+                                                                           dev_keys_out, nullptr);
+    (void)hipMemcpy(sorted_keys_out, seq.sorted_keys, sizeof(KeyT) * key_count, hipMemcpyDeviceToHost);
+    (void)hipFree(dev_keys);
+    (void)hipFree(dev_keys_out);
+}
+
+template <typename KeyT, typename ValueT>
+void rdxsrt_unstable_sort_pairs(KeyT *keys, ValueT *values, const unsigned long long key_count, KeyT *sorted_keys_out,
+                                ValueT *sorted_values_out)
+{
+    KeyT *dk = nullptr, *dko = nullptr;
+    ValueT *dv = nullptr, *dvo = nullptr;
+    const size_t kb = sizeof(KeyT) * (key_count ? key_count : 1), vb = sizeof(ValueT) * (key_count ? key_count : 1);
+    (void)hipMalloc(&dko, kb); (void)hipMalloc(&dk, kb);
+    (void)hipMalloc(&dvo, vb); (void)hipMalloc(&dv, vb);
+    (void)hipMemcpy(dk, keys, sizeof(KeyT) * key_count, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dv, values, sizeof(ValueT) * key_count, hipMemcpyHostToDevice);
+    auto seq = rdxsrt_unstable_sort<KeyT, ValueT, unsigned int>(dk, dv, (unsigned int)key_count, dko, dvo);
+    (void)hipMemcpy(sorted_keys_out, seq.sorted_keys, sizeof(KeyT) * key_count, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(sorted_values_out, seq.sorted_values, sizeof(ValueT) * key_count, hipMemcpyDeviceToHost);
+    (void)hipFree(dk); (void)hipFree(dko); (void)hipFree(dv); (void)hipFree(dvo);
+}

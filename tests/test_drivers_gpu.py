@@ -1,0 +1,35 @@
+"""The drop-in C++ drivers built on include/gpusort.hpp run and print what the
+reference's drivers print (lsb/sort.cu:68-72,148-151; msb/src/test.cu:53-56)."""
+import json
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRV = os.path.join(ROOT, "gpu-sort_amd", "drivers")
+
+
+def _run(args):
+    exe = os.path.join(DRV, args[0])
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} not built (run __graft_entry__.build())")
+    return subprocess.run([exe] + args[1:], capture_output=True, text=True, timeout=120, check=True).stdout.splitlines()
+
+
+def test_lsb_driver_output():
+    out = _run(["lsb_sort", "--n=300000", "--t=2"])
+    assert len(out) == 4
+    for first32, js in ((out[0], out[1]), (out[2], out[3])):
+        vals = [float(x) for x in first32.split()]
+        assert len(vals) == 32 and all(a >= b for a, b in zip(vals, vals[1:]))      # keys-only sort is DESCENDING
+        assert 0.0 < vals[-1] <= vals[0] <= 1.0                                       # uniform (0,1] float keys
+        rec = json.loads(js)
+        assert set(rec) == {"time_sort_kv_gpu", "time_sort_k_gpu"} and all(v > 0 for v in rec.values())
+
+
+def test_msb_driver_output():
+    out = _run(["msb_test", "20"])
+    assert out[0].startswith("Time Sort K: ") and out[1].startswith("Time Sort KV: ")
+    assert out[2].strip() == "Adjacent inversions in result: 0"
