@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpusort.so")
+LIB_PATH = os.environ.get("GS_LIB_PATH", os.path.join(_HERE, "lib", "libgpusort.so"))   # override: experiments only
 CSRC_DIR = os.path.join(_HERE, "csrc")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
@@ -31,7 +31,7 @@ SIGNATURES = {
     "gs_msb_temp_bytes": (sz, [u64, i32]),
     "gs_msb_sort_u32": (i32, [vp, sz, vp, vp, u64, vp, vp, pp, pp, i32, vp, i32]),
     "gs_shard_histogram_u32": (i32, [vp, u64, i32, vp, i32, vp]),
-    "gs_shard_partition_u32": (i32, [vp, sz, vp, vp, vp, vp, u64, i32, vp, i32, vp, i32, vp]),
+    "gs_shard_partition_u32": (i32, [vp, sz, vp, vp, vp, vp, u64, i32, vp, i32, vp, vp, i32, vp]),
     "gs_generate_u32": (i32, [vp, u64, i32, u64, u64, i32, vp]),
     "gs_check_sorted_u32": (i32, [vp, u64, i32, vp, vp]),
     "gs_check_pairs_enumerated_u32": (i32, [vp, vp, vp, u64, vp, vp]),

@@ -29,6 +29,9 @@
 namespace gs {
 
 // ---------------------------------------------------------------- upsweep --
+#ifndef UPSWEEP_BATCH
+#define UPSWEEP_BATCH 16   // 16-byte loads in flight per lane (a tile is 32 per lane)
+#endif
 template <bool VEC>
 __global__ __launch_bounds__(LSB_THREADS) void lsb_upsweep_kernel(const uint32_t *__restrict__ keys,
                                                                   uint32_t *__restrict__ spine,
@@ -53,12 +56,12 @@ __global__ __launch_bounds__(LSB_THREADS) void lsb_upsweep_kernel(const uint32_t
         if (VEC && len == LSB_TILE) {
             const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
 #pragma unroll
-            for (int j = 0; j < LSB_TILE / 4 / WAVE; j += 8) {
-                uint4 v[8];
+            for (int j = 0; j < LSB_TILE / 4 / WAVE; j += UPSWEEP_BATCH) {
+                uint4 v[UPSWEEP_BATCH];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = src4[(j + u) * WAVE + lane];
+                for (int u = 0; u < UPSWEEP_BATCH; ++u) v[u] = src4[(j + u) * WAVE + lane];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { count(v[u].x); count(v[u].y); count(v[u].z); count(v[u].w); }
+                for (int u = 0; u < UPSWEEP_BATCH; ++u) { count(v[u].x); count(v[u].y); count(v[u].z); count(v[u].w); }
             }
         } else {
             for (uint32_t i = lane; i < len; i += WAVE) count(src[i]);
@@ -123,15 +126,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void lsb_scan_kernel(uint32_t *__rest
 //      from LDS: each lane ORs its lane bit into the wave's mask entry of its
 //      digit, reads the entry back and clears its bit again.  Both are exact;
 //      `valu_rounds` splits the 16 rounds between the two pipes;
-//   3. wave 0 turns the 8 wave histograms into tile-absolute bases (4 digits
-//      per lane, b128 LDS accesses, DPP scan) and publishes, per digit, the
-//      tile's global base = digit start + scanned chunk count + prefix16;
+//   3. the 8 wave histograms become tile-absolute bases per (wave, digit) (4 digits
+//      per lane, b128 LDS accesses, DPP scan), by wave 0 alone (keys only, 3
+//      blocks/CU) or redundantly by every wave for its own row, which removes a
+//      barrier and the serial section (pairs, 2 blocks/CU); wave 0 publishes, per
+//      digit, the tile's global base = digit start + scanned chunk count + prefix16;
 //   4. keys (and values) go to LDS at their tile rank and are read back in rank
 //      order: consecutive lanes hit consecutive addresses inside a digit run.
-// Three block barriers per tile.
+// Two (pairs) or three (keys only) block barriers per tile.
 template <bool HAS_VALUES>
 struct DownsweepSmem {
-    uint32_t whist[LSB_WAVES][RADIX];                     // wave-private digit counters -> bases
+    uint32_t whist[LSB_WAVES][RADIX];                     // wave-private digit counters
+    uint16_t wbase[HAS_VALUES ? LSB_WAVES : 1][RADIX];    // pairs: tile-absolute base of (wave, digit), < 8192
     uint32_t gbase[RADIX];                                // global offset of digit run - tile-local start
     union {                                               // the masks are dead once ranking is done
         unsigned long long wmask[LSB_WAVES][RADIX];       // wave-private lane masks per digit (zero between rounds)
@@ -163,6 +169,7 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
     const uint32_t *__restrict__ totals, PassParams p)
 {
     __shared__ __attribute__((aligned(16))) DownsweepSmem<HAS_VALUES> sm;
+    constexpr bool ALLWAVE = HAS_VALUES;   // see step 3
 
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const uint32_t full_tiles = p.n / (uint32_t)LSB_TILE;
@@ -181,6 +188,7 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
     }
 
     uint32_t *my = sm.whist[w];
+    const uint16_t *mybase = sm.wbase[w];
     unsigned long long *mm = sm.wmask[w];
     const uint32_t half_bit = 1u << (lane & 31);
     const uint32_t valu_rounds = p.valu_rounds;
@@ -238,6 +246,25 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
             tbase[3] = sp[3 * p.grid] + (pf.y >> 16);
         }
 
+        // global base of digit run = digit start + tile offset - tile-local start (wave 0, lane l: digits 4l..4l+3)
+        auto publish_gbase = [&](const uint32_t (&ex)[4], const uint32_t (&run)[4]) {
+            uint32_t g[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = dstart[q] + tbase[q] - ex[q];
+            if (TAIL) {   // keys of digit d end exactly at the inclusive total of d
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] -= run[q];
+                // padded keys inflate the count of the largest digit only, and they are never stored
+                const uint32_t pads = (uint32_t)LSB_TILE - valid, dmax = p.mask;
+                if (lane == (int)(dmax >> 2)) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((dmax & 3u) == (uint32_t)q) g[q] += pads;
+                }
+            }
+            reinterpret_cast<uint4 *>(sm.gbase)[lane] = make_uint4(g[0], g[1], g[2], g[3]);
+        };
+
         // 2. rank inside the wave (the LDS mask of round i is consumed one round later, so
         //    its latency hides behind the issue of round i+1)
 #pragma unroll
@@ -280,14 +307,17 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
         }
         __syncthreads();
 
-        // 3. wave histograms -> tile-absolute bases and global bases.  Two sweeps over
-        //    the 8 rows (b128 LDS reads are cheap) keep only one row in registers.
-        if (w == 0) {
-            uint32_t run[4] = {0, 0, 0, 0};
+        // 3. wave histograms -> tile-absolute base of every (wave, digit) + global base per digit.
+        //    4 digits per lane, b128 LDS accesses, DPP scan of the 256 digit totals.
+        if constexpr (ALLWAVE) {
+            // every wave sums the 8 rows and keeps only its own row's bases (own row of `wbase`), so
+            // there is no serial section and no second barrier: best at 2 blocks/CU (pairs)
+            uint32_t run[4] = {0, 0, 0, 0}, below[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < LSB_WAVES; ++j) {
                 const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
                 run[0] += x.x; run[1] += x.y; run[2] += x.z; run[3] += x.w;
+                if (j < w) { below[0] += x.x; below[1] += x.y; below[2] += x.z; below[3] += x.w; }
             }
             const uint32_t lane_sum = run[0] + run[1] + run[2] + run[3];
             uint32_t ex[4];
@@ -295,37 +325,44 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
             ex[1] = ex[0] + run[0];
             ex[2] = ex[1] + run[1];
             ex[3] = ex[2] + run[2];
-            uint32_t g[4];
+            reinterpret_cast<uint2 *>(sm.wbase[w])[lane] =
+                make_uint2((ex[0] + below[0]) | ((ex[1] + below[1]) << 16), (ex[2] + below[2]) | ((ex[3] + below[3]) << 16));
+            if (w == 0) publish_gbase(ex, run);
+        } else {
+            // wave 0 alone, two sweeps over the 8 rows (only one row in registers at a time), bases
+            // written back in place; the other waves wait at the barrier while the CU's other two
+            // blocks run: best at 3 blocks/CU (keys only)
+            if (w == 0) {
+                uint32_t run[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) g[q] = dstart[q] + tbase[q] - ex[q];
-            if (TAIL) {   // keys of digit d end exactly at the inclusive total of d
+                for (int j = 0; j < LSB_WAVES; ++j) {
+                    const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
+                    run[0] += x.x; run[1] += x.y; run[2] += x.z; run[3] += x.w;
+                }
+                const uint32_t lane_sum = run[0] + run[1] + run[2] + run[3];
+                uint32_t ex[4];
+                ex[0] = wave_inclusive_scan(lane_sum) - lane_sum;
+                ex[1] = ex[0] + run[0];
+                ex[2] = ex[1] + run[1];
+                ex[3] = ex[2] + run[2];
+                publish_gbase(ex, run);
+                asm volatile("" ::: "memory");   // re-read the rows instead of keeping 32 registers live
+                uint4 e4 = make_uint4(ex[0], ex[1], ex[2], ex[3]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] -= run[q];
-                // padded keys inflate the count of the largest digit only, and they are never stored
-                const uint32_t pads = (uint32_t)LSB_TILE - valid, dmax = p.mask;
-                if (lane == (int)(dmax >> 2)) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if ((dmax & 3u) == (uint32_t)q) g[q] += pads;
+                for (int j = 0; j < LSB_WAVES; ++j) {
+                    const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
+                    reinterpret_cast<uint4 *>(sm.whist[j])[lane] = e4;
+                    e4.x += x.x; e4.y += x.y; e4.z += x.z; e4.w += x.w;
                 }
             }
-            reinterpret_cast<uint4 *>(sm.gbase)[lane] = make_uint4(g[0], g[1], g[2], g[3]);
-            asm volatile("" ::: "memory");   // re-read the rows instead of keeping 32 registers live
-            uint4 e4 = make_uint4(ex[0], ex[1], ex[2], ex[3]);
-#pragma unroll
-            for (int j = 0; j < LSB_WAVES; ++j) {
-                const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
-                reinterpret_cast<uint4 *>(sm.whist[j])[lane] = e4;
-                e4.x += x.x; e4.y += x.y; e4.z += x.z; e4.w += x.w;
-            }
+            __syncthreads();
         }
-        __syncthreads();
 
         // 4. tile -> LDS in rank order -> global
 #pragma unroll
         for (int i = 0; i < LSB_KPT; ++i) {
             const uint32_t d = __builtin_amdgcn_ubfe(key[i], p.shift, p.bits);
-            const uint32_t at = pos[i] + my[d];
+            const uint32_t at = pos[i] + (ALLWAVE ? (uint32_t)mybase[d] : my[d]);
             if (HAS_VALUES) reinterpret_cast<uint2 *>(sm.stage)[at] = make_uint2(key[i], val[i]);
             else sm.stage[at] = key[i];
         }

@@ -269,8 +269,8 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
 
 // ---------------------------------------------------------------- scatter --
 // M6: unstable counting-sort scatter of one tile on byte `shift/8`.  Ranks inside the
-// tile come from LDS atomics (one fetch-add per key, a single one per wave when all 64
-// lanes hold the same digit -- the hot-bucket case), the tile's slice of every
+// tile come from wave-aggregated LDS atomics (ballot match, one fetch-add per distinct
+// digit and wave -- a hot bucket costs one atomic per wave), the tile's slice of every
 // sub-bucket is reserved with one global atomic per digit (M6: inter-block order is
 // not deterministic), and the keys go through LDS so each digit run is written with
 // consecutive lanes on consecutive addresses.
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(MSB_THREADS, 4) void msb_scatter_kernel(MsbWs ws, i
     __shared__ uint32_t stage[MSB_TILE * (HAS_VALUES ? 2 : 1)];
     const unsigned long long packed = ws.level[L].packed;
     const uint32_t nb = (uint32_t)(packed >> 32), ntiles = (uint32_t)packed;
-    const int tid = threadIdx.x, lane = lane_id();
+    const int tid = threadIdx.x;
     const MsbBucket *bk = ws.buckets[L & 1];
     for (uint32_t g = blockIdx.x; g < ntiles; g += gridDim.x) {
     const uint32_t b = msb_find_bucket(bk, nb, g);
@@ -309,15 +309,19 @@ __global__ __launch_bounds__(MSB_THREADS, 4) void msb_scatter_kernel(MsbWs ws, i
         const uint32_t idx = (uint32_t)tid + i * MSB_THREADS;
         const bool ok = idx < valid;
         const uint32_t d = digit_of(ds, key[i]);
-        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-        if (__builtin_amdgcn_ballot_w64(ok && d == d0) == ~0ull) {
-            // whole wave on one digit: one atomic for 64 keys
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&lcnt[d0], 64u);
-            rnk[i] = __builtin_amdgcn_readfirstlane(base) + (uint32_t)lane;
-        } else {
-            rnk[i] = ok ? atomicAdd(&lcnt[d], 1u) : 0u;
-        }
+        // wave-aggregated rank: the lanes holding the same digit (ballot match) take consecutive
+        // ranks from ONE fetch-add issued by the group's first lane, so a hot digit costs one LDS
+        // atomic per wave instead of 64 colliding ones
+        uint32_t plo, phi;
+        match_digit(d, plo, phi);
+        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
+        plo &= (uint32_t)okm;
+        phi &= (uint32_t)(okm >> 32);
+        const uint32_t lower = count_lower(plo, phi);
+        uint32_t base = 0;
+        if (ok && lower == 0) base = atomicAdd(&lcnt[d], (uint32_t)(__popc(plo) + __popc(phi)));
+        const int leader = plo ? __builtin_ctz(plo) : 32 + __builtin_ctz(phi | 0x80000000u);
+        rnk[i] = (uint32_t)__shfl((int)base, leader, WAVE) + lower;
     }
     __syncthreads();
     {
@@ -473,6 +477,7 @@ __global__ __launch_bounds__(MSB_THREADS, 4) void msb_local_sort_kernel(MsbWs ws
 constexpr int SHARD_MAX_BITS = 12;   // 4096 bins of the key space: 16 KiB of LDS counters
 
 // 2^bits-bin histogram of the keys' top bits (after the order-preserving twiddle), u64 counts
+template <bool VEC>
 __global__ __launch_bounds__(MSB_THREADS) void shard_hist_kernel(const uint32_t *__restrict__ keys, uint64_t n, int bits,
                                                                  unsigned long long *__restrict__ hist, int f32_in,
                                                                  uint32_t xor_in)
@@ -482,9 +487,25 @@ __global__ __launch_bounds__(MSB_THREADS) void shard_hist_kernel(const uint32_t 
     for (uint32_t i = threadIdx.x; i < nb; i += MSB_THREADS) lh[i] = 0;
     __syncthreads();
     const int rshift = 32 - bits;
+    auto count = [&](uint32_t k) { atomicAdd(&lh[twiddle_in(k, f32_in, xor_in) >> rshift], 1u); };
     // a block never counts more than 2^32 keys (n < 2^32 per call site), so u32 LDS counters suffice
-    for (uint64_t i = (uint64_t)blockIdx.x * MSB_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * MSB_THREADS)
-        atomicAdd(&lh[twiddle_in(keys[i], f32_in, xor_in) >> rshift], 1u);
+    const uint64_t stride = (uint64_t)gridDim.x * MSB_THREADS;
+    uint64_t done = 0;
+    if (VEC) {
+        const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+        const uint64_t nvec = n >> 2;
+        uint64_t v = (uint64_t)blockIdx.x * MSB_THREADS + threadIdx.x;
+        for (; v + 3 * stride < nvec; v += 4 * stride) {
+            const uint4 a = k4[v], b = k4[v + stride], c = k4[v + 2 * stride], d = k4[v + 3 * stride];
+            count(a.x); count(a.y); count(a.z); count(a.w);
+            count(b.x); count(b.y); count(b.z); count(b.w);
+            count(c.x); count(c.y); count(c.z); count(c.w);
+            count(d.x); count(d.y); count(d.z); count(d.w);
+        }
+        for (; v < nvec; v += stride) { const uint4 a = k4[v]; count(a.x); count(a.y); count(a.z); count(a.w); }
+        done = nvec << 2;
+    }
+    for (uint64_t i = done + (uint64_t)blockIdx.x * MSB_THREADS + threadIdx.x; i < n; i += stride) count(keys[i]);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nb; i += MSB_THREADS)
         if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
@@ -493,6 +514,28 @@ __global__ __launch_bounds__(MSB_THREADS) void shard_hist_kernel(const uint32_t 
 __global__ void shard_counts_kernel(const uint32_t *__restrict__ row, int num_ranks, unsigned long long *__restrict__ counts)
 {
     if ((int)threadIdx.x < num_ranks) counts[threadIdx.x] = row[threadIdx.x];
+}
+
+// destination counts and scatter cursors from the bin histogram (no second pass over the keys)
+__global__ __launch_bounds__(256) void shard_cursors_kernel(const unsigned long long *__restrict__ bin_hist,
+                                                            const uint8_t *__restrict__ dest_of_bin, uint32_t nbins,
+                                                            int num_ranks, uint32_t *__restrict__ row,
+                                                            unsigned long long *__restrict__ counts)
+{
+    __shared__ uint32_t cnt[RADIX];
+    __shared__ uint32_t scratch[8];
+    const int d = threadIdx.x;
+    cnt[d] = 0;
+    __syncthreads();
+    for (uint32_t b = d; b < nbins; b += 256) {
+        const uint32_t c = (uint32_t)bin_hist[b];
+        if (c) atomicAdd(&cnt[dest_of_bin[b]], c);
+    }
+    __syncthreads();
+    const uint32_t c = cnt[d];
+    const uint32_t ex = block_exclusive_scan_256(c, scratch, nullptr);
+    row[d] = ex;
+    if (d < num_ranks) counts[d] = c;
 }
 
 // ------------------------------------------------------------------- host --
@@ -626,14 +669,20 @@ int gs_shard_histogram_u32(const uint32_t *d_keys, uint64_t num_items, int bits,
     lsb_twiddle_masks(key_type, 0, true, true, tw);
     const uint64_t blocks = (num_items + MSB_TILE - 1) / MSB_TILE;
     KernelTimer kt(GS_K_SHARD, s);
-    hipLaunchKernelGGL(shard_hist_kernel, dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(MSB_THREADS), 0, s, d_keys,
-                       num_items, bits, (unsigned long long *)d_hist, tw.f32_in, tw.xor_in);
+    const dim3 grid((uint32_t)(blocks < 2048 ? blocks : 2048)), block(MSB_THREADS);
+    if (((uintptr_t)d_keys & 15u) == 0)
+        hipLaunchKernelGGL(shard_hist_kernel<true>, grid, block, 0, s, d_keys, num_items, bits, (unsigned long long *)d_hist,
+                           tw.f32_in, tw.xor_in);
+    else
+        hipLaunchKernelGGL(shard_hist_kernel<false>, grid, block, 0, s, d_keys, num_items, bits,
+                           (unsigned long long *)d_hist, tw.f32_in, tw.xor_in);
     return (int)hipGetLastError();
 }
 
 int gs_shard_partition_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys_in, uint32_t *d_keys_out,
                            const uint32_t *d_vals_in, uint32_t *d_vals_out, uint64_t num_items, int bits,
-                           const uint8_t *d_dest_of_bin, int num_ranks, uint64_t *d_counts, int key_type, void *stream)
+                           const uint8_t *d_dest_of_bin, int num_ranks, const uint64_t *d_bin_hist, uint64_t *d_counts,
+                           int key_type, void *stream)
 {
     if (bits < 1 || bits > SHARD_MAX_BITS || num_ranks < 1 || num_ranks > RADIX || !d_dest_of_bin || !d_counts)
         return hipErrorInvalidValue;
@@ -654,14 +703,20 @@ int gs_shard_partition_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_ke
     const uint32_t tiles = (n + MSB_TILE - 1) / MSB_TILE;
     const uint32_t grid = tiles < MSB_MAX_GRID ? tiles : MSB_MAX_GRID;
     KernelTimer kt(GS_K_SHARD, s);
-    // one bucket = the whole shard, "digit" = destination rank: histogram, cursors, unstable scatter
+    // one bucket = the whole shard, "digit" = destination rank: counts -> cursors -> unstable scatter
     hipLaunchKernelGGL(msb_init_kernel, dim3(1), dim3(64), 0, s, ws, n);
-    hipMemsetAsync(ws.hist[0], 0, RADIX * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(msb_hist_kernel, dim3(grid), dim3(MSB_THREADS), 0, s, ws, 0, d_keys_in, dsel);
-    hipLaunchKernelGGL(shard_counts_kernel, dim3(1), dim3(RADIX), 0, s, (const uint32_t *)ws.hist[0], num_ranks,
-                       (unsigned long long *)d_counts);
-    hipLaunchKernelGGL(msb_classify_kernel<true>, dim3(1), dim3(256), 0, s, ws, 0 /* cursors only */,
-                       (const uint32_t *)nullptr, 0);
+    if (d_bin_hist) {
+        // the caller already has the bin histogram of these keys (gs_shard_histogram_u32)
+        hipLaunchKernelGGL(shard_cursors_kernel, dim3(1), dim3(256), 0, s, (const unsigned long long *)d_bin_hist,
+                           d_dest_of_bin, 1u << bits, num_ranks, ws.hist[0], (unsigned long long *)d_counts);
+    } else {
+        hipMemsetAsync(ws.hist[0], 0, RADIX * sizeof(uint32_t), s);
+        hipLaunchKernelGGL(msb_hist_kernel, dim3(grid), dim3(MSB_THREADS), 0, s, ws, 0, d_keys_in, dsel);
+        hipLaunchKernelGGL(shard_counts_kernel, dim3(1), dim3(RADIX), 0, s, (const uint32_t *)ws.hist[0], num_ranks,
+                           (unsigned long long *)d_counts);
+        hipLaunchKernelGGL(msb_classify_kernel<true>, dim3(1), dim3(256), 0, s, ws, 0 /* cursors only */,
+                           (const uint32_t *)nullptr, 0);
+    }
     if (pairs)
         hipLaunchKernelGGL(msb_scatter_kernel<true>, dim3(grid), dim3(MSB_THREADS), 0, s, ws, 0, d_keys_in, d_keys_out, d_vals_in,
                            d_vals_out, dsel, 0, 0u);

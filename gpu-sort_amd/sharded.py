@@ -61,13 +61,15 @@ class DeviceOps:
                                                    self._sp(None)), "gs_shard_histogram_u32")
         return hist
 
-    def partition(self, keys, vals, n, bits, dest_np, world, temp, keys_out, vals_out):
+    def partition(self, keys, vals, n, bits, dest_np, world, temp, keys_out, vals_out, bin_hist=None):
         dest = torch.from_numpy(dest_np).to(self.device)
         counts = torch.empty(world, dtype=torch.int64, device=self.device)
         self.check(self.lib.gs_shard_partition_u32(temp.data_ptr(), temp.numel(), keys.data_ptr(), keys_out.data_ptr(),
                                                    vals.data_ptr() if vals is not None else None,
                                                    vals_out.data_ptr() if vals is not None else None, n, bits,
-                                                   dest.data_ptr(), world, counts.data_ptr(), self._lib.GS_KEY_U32,
+                                                   dest.data_ptr(), world,
+                                                   bin_hist.data_ptr() if bin_hist is not None else None,
+                                                   counts.data_ptr(), self._lib.GS_KEY_U32,
                                                    self._sp(None)), "gs_shard_partition_u32")
         return counts
 
@@ -137,7 +139,7 @@ class ShardedSorter:
         m = int(recv.sum())
         if m > self.cap:
             self._alloc(int(m * 1.1) + 4096)
-        self.ops.partition(keys, vals, n, SHARD_BITS, dest, world, self.temp, self.part_k, self.part_v)
+        self.ops.partition(keys, vals, n, SHARD_BITS, dest, world, self.temp, self.part_k, self.part_v, bin_hist=hist)
         if world > 1:
             dist.all_to_all_single(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), group=self.group)
             if self.pairs:

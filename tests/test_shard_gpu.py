@@ -26,7 +26,7 @@ def test_histogram_and_partition(gs, cuda, oracle, n, dist_kind):
     dest, per_rank = sharded.compute_splits(np.tile(hist, (world, 1)), world)
     temp = torch.empty(ops.temp_bytes(max(n, 1), True), dtype=torch.uint8, device=cuda)
     ko, vo = ops.empty(n), ops.empty(n)
-    counts = ops.partition(dk, dv, n, bits, dest, world, temp, ko, vo).cpu().numpy()
+    counts = ops.partition(dk, dv, n, bits, dest, world, temp, ko, vo, bin_hist=ops.histogram(dk, n, bits)).cpu().numpy()
     torch.cuda.synchronize()
     d = dest[keys >> np.uint32(32 - bits)] if n else np.zeros(0, np.uint8)
     assert np.array_equal(counts, np.bincount(d, minlength=world))

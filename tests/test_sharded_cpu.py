@@ -29,7 +29,7 @@ class NumpyOps:
         h = np.bincount(self._u32(keys, n) >> np.uint32(32 - bits), minlength=1 << bits).astype(np.int64)
         return torch.from_numpy(h)
 
-    def partition(self, keys, vals, n, bits, dest_np, world, temp, keys_out, vals_out):
+    def partition(self, keys, vals, n, bits, dest_np, world, temp, keys_out, vals_out, bin_hist=None):
         k = self._u32(keys, n)
         d = dest_np[k >> np.uint32(32 - bits)]
         order = np.argsort(d, kind="stable")
