@@ -30,6 +30,11 @@ __device__ __forceinline__ uint32_t twiddle_out(uint32_t k, int f32, uint32_t x)
     return k;
 }
 
+__device__ __forceinline__ uint32_t count_lower_mask(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // Lanes of this wave whose 8-bit digit equals mine (all 64 lanes must be
 // active), as two 32-bit mask halves.  Per digit bit: v_bfe_i32 replicates my
 // bit to 32 bits (s), v_cmp ballots it into an SGPR pair (m), and one
@@ -83,6 +88,20 @@ __device__ __forceinline__ void match_digit(uint32_t d, uint32_t &lo, uint32_t &
 __device__ __forceinline__ uint32_t count_lower(uint32_t lo, uint32_t hi)
 {
     return __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+}
+
+// histogram increment that stays cheap under skew: when every active lane of the wave
+// holds the same digit (a hot bucket) one lane adds the lane count, otherwise each lane
+// adds 1 (LDS atomic; same-address lanes serialise, so the uniform case must not collide)
+__device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t d)
+{
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+    const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+    if (__builtin_amdgcn_ballot_w64(d == d0) == act) {
+        if (count_lower_mask(act) == 0) atomicAdd(&hist[d0], (uint32_t)__popcll(act));
+    } else {
+        atomicAdd(&hist[d], 1u);
+    }
 }
 
 // popcount of `mask` restricted to lanes below mine

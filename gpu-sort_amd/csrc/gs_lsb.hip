@@ -51,7 +51,7 @@ __global__ __launch_bounds__(LSB_THREADS) void lsb_upsweep_kernel(const uint32_t
         const uint32_t *src = keys + lo;
         auto count = [&](uint32_t raw) {
             const uint32_t k = twiddle_in(raw, p.f32_in, p.xor_in);
-            atomicAdd(&my[__builtin_amdgcn_ubfe(k, p.shift, p.bits)], 1u);   // wave-private: ds_add_u32
+            hist_add(my, __builtin_amdgcn_ubfe(k, p.shift, p.bits));        // wave-private ds_add_u32
         };
         if (VEC && len == LSB_TILE) {
             const uint4 *src4 = reinterpret_cast<const uint4 *>(src);

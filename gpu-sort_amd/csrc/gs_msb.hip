@@ -158,8 +158,19 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_hist_kernel(MsbWs ws, int L, 
 #pragma unroll
         for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
         const uint32_t *p = src + lo;
-        for (uint32_t i = (uint32_t)w * WAVE + lane; i < len; i += MSB_THREADS)
-            atomicAdd(&my[digit_of(ds, p[i])], 1u);
+        // 16-byte loads over the aligned middle of the tile, scalar head and tail
+        uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) >> 2;
+        if (head > len) head = len;
+        const uint32_t nvec = (len - head) >> 2;
+        const uint4 *p4 = reinterpret_cast<const uint4 *>(p + head);
+        for (uint32_t v = (uint32_t)tid; v < nvec; v += MSB_THREADS) {
+            const uint4 q = p4[v];
+            hist_add(my, digit_of(ds, q.x)); hist_add(my, digit_of(ds, q.y));
+            hist_add(my, digit_of(ds, q.z)); hist_add(my, digit_of(ds, q.w));
+        }
+        if ((uint32_t)tid < head) hist_add(my, digit_of(ds, p[tid]));
+        const uint32_t tail0 = head + (nvec << 2);
+        if (tail0 + (uint32_t)tid < len) hist_add(my, digit_of(ds, p[tail0 + tid]));
         __syncthreads();
         if (tid < RADIX) {
             uint32_t s = 0;
@@ -365,8 +376,8 @@ __global__ __launch_bounds__(MSB_THREADS, 4) void msb_scatter_kernel(MsbWs ws, i
 }
 
 // ------------------------------------------------------------- local sort --
-// M7: finish one range of <= KPT*512 keys inside a workgroup: stable LSD passes of 8
-// bits over its low `sort_bits` bits, entirely in registers + LDS, then one coalesced
+// M7: finish one range of <= KPT*512 keys inside a workgroup: LSD passes of 8 bits (the
+// first by atomic counting, the rest stable) over its low `sort_bits` bits, entirely in registers + LDS, then one coalesced
 // store to the result buffer.  Ranking per pass is the LSB downsweep's: wave64
 // ballot/popcount match + wave-private LDS histogram, wave 0 scans the 8 histograms.
 template <int KPT, bool HAS_VALUES>
@@ -403,16 +414,34 @@ __global__ __launch_bounds__(MSB_THREADS, 4) void msb_local_sort_kernel(MsbWs ws
     for (uint32_t shift = 0; shift < T.sort_bits; shift += 8) {
 #pragma unroll
         for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
+        if (shift == 0) {
+            // the first LSD pass need not be stable (nothing is ordered yet; the reference does the
+            // same, cuda_radix_sort.h:1419-1481): rank = fetch-add on the wave's digit counter,
+            // one add for the whole wave when all 64 lanes hold the same digit
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const uint32_t d = (key[i] >> shift) & 255u;
-            uint32_t plo, phi;
-            match_digit(d, plo, phi);
-            const uint32_t lower = count_lower(plo, phi);
-            pos[i] = my[d] + lower;
-            if (lower == 0)
-                __hip_atomic_fetch_add(&my[d], (uint32_t)(__popc(plo) + __popc(phi)), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t d = key[i] & 255u;
+                const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+                if (__builtin_amdgcn_ballot_w64(d == d0) == ~0ull) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&my[d0], 64u);
+                    pos[i] = __builtin_amdgcn_readfirstlane(base) + (uint32_t)lane;
+                } else {
+                    pos[i] = atomicAdd(&my[d], 1u);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t d = (key[i] >> shift) & 255u;
+                uint32_t plo, phi;
+                match_digit(d, plo, phi);
+                const uint32_t lower = count_lower(plo, phi);
+                pos[i] = my[d] + lower;
+                if (lower == 0)
+                    __hip_atomic_fetch_add(&my[d], (uint32_t)(__popc(plo) + __popc(phi)), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
         }
 #pragma unroll
         for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]), "+v"(key[i]));
