@@ -23,6 +23,8 @@ SIGNATURES = {
     "gs_error_string": (C.c_char_p, [i32]),
     "gs_lsb_temp_bytes": (sz, [u64, i32]),
     "gs_lsb_sort_u32": (i32, [vp, sz, pp, pp, C.POINTER(i32), u64, i32, i32, i32, i32, vp]),
+    "gs_lsb_copy_temp_bytes": (sz, [u64, i32]),
+    "gs_lsb_sort_copy_u32": (i32, [vp, sz, vp, vp, vp, vp, u64, i32, i32, i32, i32, vp]),
     "gs_lsb_geometry": (None, [u64, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gs_lsb_workspace_layout": (i32, [vp, u64, pp, pp, pp]),
     "gs_lsb_upsweep_u32": (i32, [vp, sz, vp, u64, i32, i32, i32, i32, vp]),

@@ -55,13 +55,19 @@ __global__ __launch_bounds__(LSB_THREADS) void lsb_upsweep_kernel(const uint32_t
         };
         if (VEC && len == LSB_TILE) {
             const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+            constexpr int NV = LSB_TILE / 4 / WAVE;       // 16-byte loads per lane and tile
 #pragma unroll
-            for (int j = 0; j < LSB_TILE / 4 / WAVE; j += UPSWEEP_BATCH) {
+            for (int j = 0; j + UPSWEEP_BATCH <= NV; j += UPSWEEP_BATCH) {
                 uint4 v[UPSWEEP_BATCH];
 #pragma unroll
                 for (int u = 0; u < UPSWEEP_BATCH; ++u) v[u] = src4[(j + u) * WAVE + lane];
 #pragma unroll
                 for (int u = 0; u < UPSWEEP_BATCH; ++u) { count(v[u].x); count(v[u].y); count(v[u].z); count(v[u].w); }
+            }
+#pragma unroll
+            for (int j = NV - NV % UPSWEEP_BATCH; j < NV; ++j) {
+                const uint4 v = src4[j * WAVE + lane];
+                count(v.x); count(v.y); count(v.z); count(v.w);
             }
         } else {
             for (uint32_t i = lane; i < len; i += WAVE) count(src[i]);
@@ -486,6 +492,30 @@ int lsb_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint
     return (int)hipGetLastError();
 }
 
+// shared pass loop: src/dst pointers per pass are chosen by `route`
+template <typename Route>
+static int lsb_run_passes(const LsbWorkspace &ws, uint64_t num_items, int begin_bit, int end_bit, int descending,
+                          int key_type, bool pairs, hipStream_t s, Route route)
+{
+    const int num_bits = end_bit - begin_bit;
+    const int num_passes = (num_bits + RADIX_BITS - 1) / RADIX_BITS;
+    for (int pass = 0; pass < num_passes; ++pass) {
+        const int shift = begin_bit + pass * RADIX_BITS;
+        const int bits = (end_bit - shift < RADIX_BITS) ? end_bit - shift : RADIX_BITS;
+        PassParams p = lsb_make_params(num_items, shift, bits);
+        lsb_twiddle_masks(key_type, descending, pass == 0, pass == num_passes - 1, p);
+        const uint32_t *kin, *vin;
+        uint32_t *kout, *vout;
+        route(pass, num_passes, kin, kout, vin, vout);
+        if (!pairs) { vin = nullptr; vout = nullptr; }
+        int e;
+        if ((e = lsb_upsweep(kin, ws.spine, ws.prefix16, p, s))) return e;
+        if ((e = lsb_scan(ws.spine, ws.totals, p.grid, s))) return e;
+        if ((e = lsb_downsweep(kin, kout, vin, vout, ws.spine, ws.prefix16, ws.totals, p, s))) return e;
+    }
+    return hipSuccess;
+}
+
 }  // namespace gs
 
 using namespace gs;
@@ -565,28 +595,62 @@ int gs_lsb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], uint32
     if (!d_temp || temp_bytes < gs_lsb_temp_bytes(num_items, d_vals != nullptr)) return hipErrorInvalidValue;
     if (!d_keys[0] || !d_keys[1] || (d_vals && (!d_vals[0] || !d_vals[1]))) return hipErrorInvalidValue;
 
-    hipStream_t s = (hipStream_t)stream;
     const LsbWorkspace ws = lsb_carve(d_temp, num_items);
-    const int num_bits = end_bit - begin_bit;
-    const int num_passes = (num_bits + RADIX_BITS - 1) / RADIX_BITS;
     int sel = *selector;
-    for (int pass = 0; pass < num_passes; ++pass) {
-        const int shift = begin_bit + pass * RADIX_BITS;
-        const int bits = (end_bit - shift < RADIX_BITS) ? end_bit - shift : RADIX_BITS;
-        PassParams p = lsb_make_params(num_items, shift, bits);
-        lsb_twiddle_masks(key_type, descending, pass == 0, pass == num_passes - 1, p);
-        const uint32_t *kin = d_keys[sel];
-        uint32_t *kout = d_keys[sel ^ 1];
-        const uint32_t *vin = d_vals ? d_vals[sel] : nullptr;
-        uint32_t *vout = d_vals ? d_vals[sel ^ 1] : nullptr;
-        int e;
-        if ((e = lsb_upsweep(kin, ws.spine, ws.prefix16, p, s))) return e;
-        if ((e = lsb_scan(ws.spine, ws.totals, p.grid, s))) return e;
-        if ((e = lsb_downsweep(kin, kout, vin, vout, ws.spine, ws.prefix16, ws.totals, p, s))) return e;
-        sel ^= 1;
-    }
+    const int e = lsb_run_passes(ws, num_items, begin_bit, end_bit, descending, key_type, d_vals != nullptr,
+                                 (hipStream_t)stream,
+                                 [&](int, int, const uint32_t *&kin, uint32_t *&kout, const uint32_t *&vin, uint32_t *&vout) {
+                                     kin = d_keys[sel]; kout = d_keys[sel ^ 1];
+                                     vin = d_vals ? d_vals[sel] : nullptr; vout = d_vals ? d_vals[sel ^ 1] : nullptr;
+                                     sel ^= 1;
+                                 });
+    if (e) return e;
     *selector = sel;
     return hipSuccess;
+}
+
+// Non-overwriting form: the input arrays stay untouched and the result lands in the
+// output arrays; the extra ping-pong buffers live in the workspace (CUB's
+// is_overwrite_okay == false, dispatch_radix_sort.cuh:1099-1129).
+size_t gs_lsb_copy_temp_bytes(uint64_t num_items, int has_values)
+{
+    const size_t buf = align256((size_t)num_items * sizeof(uint32_t));
+    return align256(lsb_temp_bytes(num_items)) + buf * (has_values ? 2 : 1);
+}
+
+int gs_lsb_sort_copy_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys_in, uint32_t *d_keys_out,
+                         const uint32_t *d_vals_in, uint32_t *d_vals_out, uint64_t num_items, int begin_bit, int end_bit,
+                         int descending, int key_type, void *stream)
+{
+    if (begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) return hipErrorInvalidValue;
+    if (num_items >= (1ull << 32)) return hipErrorInvalidValue;
+    if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;
+    if ((d_vals_in == nullptr) != (d_vals_out == nullptr)) return hipErrorInvalidValue;
+    if (num_items == 0) return hipSuccess;
+    const bool pairs = d_vals_in != nullptr;
+    if (!d_keys_in || !d_keys_out) return hipErrorInvalidValue;
+    if (!d_temp || temp_bytes < gs_lsb_copy_temp_bytes(num_items, pairs)) return hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    if (begin_bit == end_bit) {   // zero passes: the output is a copy of the input
+        hipError_t e = hipMemcpyAsync(d_keys_out, d_keys_in, num_items * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess && pairs)
+            e = hipMemcpyAsync(d_vals_out, d_vals_in, num_items * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+        return (int)e;
+    }
+    const LsbWorkspace ws = lsb_carve(d_temp, num_items);
+    const size_t buf = align256((size_t)num_items * sizeof(uint32_t));
+    uint32_t *tk = (uint32_t *)((char *)d_temp + align256(lsb_temp_bytes(num_items)));
+    uint32_t *tv = (uint32_t *)((char *)tk + buf);
+    return lsb_run_passes(ws, num_items, begin_bit, end_bit, descending, key_type, pairs, s,
+                          [&](int pass, int num_passes, const uint32_t *&kin, uint32_t *&kout, const uint32_t *&vin,
+                              uint32_t *&vout) {
+                              // pass k writes OUT when an even number of passes follows it, else the scratch
+                              const bool to_out = ((num_passes - 1 - pass) & 1) == 0;
+                              kin = (pass == 0) ? d_keys_in : (to_out ? tk : d_keys_out);
+                              vin = (pass == 0) ? d_vals_in : (to_out ? tv : d_vals_out);
+                              kout = to_out ? d_keys_out : tk;
+                              vout = to_out ? d_vals_out : tv;
+                          });
 }
 
 }  // extern "C"

@@ -79,6 +79,44 @@ class DeviceRadixSort:
         return need
 
     @staticmethod
+    def _sort_copy(d_temp_storage, temp_storage_bytes, d_keys_in, d_keys_out, d_values_in, d_values_out, num_items,
+                   begin_bit, end_bit, descending, stream, key_type):
+        """Plain-pointer overloads (device_radix_sort.cuh:156-180, 503-527): input untouched, result in *_out."""
+        has_values = d_values_in is not None
+        need = lib.gs_lsb_copy_temp_bytes(num_items, int(has_values))
+        if d_temp_storage is None:
+            return need
+        if end_bit is None:
+            end_bit = 32
+        if key_type is None:
+            key_type = _KEY_TYPES.get(d_keys_in.dtype, _lib.GS_KEY_U32)
+        _check_buf(d_keys_in, num_items, "d_keys_in")
+        _check_buf(d_keys_out, num_items, "d_keys_out")
+        if has_values:
+            _check_buf(d_values_in, num_items, "d_values_in")
+            _check_buf(d_values_out, num_items, "d_values_out")
+        err = lib.gs_lsb_sort_copy_u32(C.c_void_p(d_temp_storage.data_ptr()),
+                                       min(temp_storage_bytes, d_temp_storage.numel() * d_temp_storage.element_size()),
+                                       d_keys_in.data_ptr(), d_keys_out.data_ptr(),
+                                       d_values_in.data_ptr() if has_values else None,
+                                       d_values_out.data_ptr() if has_values else None, num_items, begin_bit, end_bit,
+                                       int(descending), key_type, _stream_ptr(stream))
+        check(err, "gs_lsb_sort_copy_u32")
+        return need
+
+    @staticmethod
+    def SortKeysCopy(d_temp_storage, temp_storage_bytes, d_keys_in, d_keys_out, num_items, begin_bit=0, end_bit=None,
+                     stream=None, key_type=None, descending=False):
+        return DeviceRadixSort._sort_copy(d_temp_storage, temp_storage_bytes, d_keys_in, d_keys_out, None, None,
+                                          num_items, begin_bit, end_bit, descending, stream, key_type)
+
+    @staticmethod
+    def SortPairsCopy(d_temp_storage, temp_storage_bytes, d_keys_in, d_keys_out, d_values_in, d_values_out, num_items,
+                      begin_bit=0, end_bit=None, stream=None, key_type=None, descending=False):
+        return DeviceRadixSort._sort_copy(d_temp_storage, temp_storage_bytes, d_keys_in, d_keys_out, d_values_in,
+                                          d_values_out, num_items, begin_bit, end_bit, descending, stream, key_type)
+
+    @staticmethod
     def SortKeys(d_temp_storage, temp_storage_bytes, d_keys, num_items, begin_bit=0, end_bit=None, stream=None,
                  key_type=None):
         return DeviceRadixSort._sort(d_temp_storage, temp_storage_bytes, d_keys, None, num_items, begin_bit, end_bit,

@@ -68,6 +68,18 @@ int gs_lsb_sort_u32(void *d_temp, size_t temp_bytes,
                     uint64_t num_items, int begin_bit, int end_bit,
                     int descending, int key_type, void *stream);
 
+/* Non-overwriting form (the plain-pointer overloads of cub::DeviceRadixSort,
+ * lsb/cub/cub/device/device_radix_sort.cuh:156-180,503-527 with
+ * is_overwrite_okay == false, dispatch_radix_sort.cuh:1099-1129): the input
+ * arrays are left untouched, the result is written to d_*_out, and the extra
+ * ping-pong buffers are part of the workspace.                              */
+size_t gs_lsb_copy_temp_bytes(uint64_t num_items, int has_values);
+int gs_lsb_sort_copy_u32(void *d_temp, size_t temp_bytes,
+                         const uint32_t *d_keys_in, uint32_t *d_keys_out,
+                         const uint32_t *d_vals_in, uint32_t *d_vals_out,
+                         uint64_t num_items, int begin_bit, int end_bit,
+                         int descending, int key_type, void *stream);
+
 /* Bring-up / test access to the three kernels of one pass (SURVEY.md 8a rows
  * L4-L6), all working on the same d_temp workspace (gs_lsb_temp_bytes):
  *   upsweep   -> spine[digit*grid + chunk] (u32 counts per chunk of

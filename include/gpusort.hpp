@@ -72,6 +72,42 @@ struct DeviceRadixSort {
         return static_cast<hipError_t>(err);
     }
 
+    // plain-pointer overloads: input untouched, result in *_out (device_radix_sort.cuh:156-180, 503-527)
+    template <typename KeyT, typename ValueT>
+    static hipError_t DispatchCopy(void *d_temp_storage, size_t &temp_storage_bytes, const KeyT *d_keys_in,
+                                   KeyT *d_keys_out, const ValueT *d_values_in, ValueT *d_values_out, int num_items,
+                                   int begin_bit, int end_bit, bool descending, hipStream_t stream)
+    {
+        static_assert(sizeof(KeyT) == 4, "32-bit keys only");
+        const bool pairs = d_values_in != nullptr;
+        if (d_temp_storage == nullptr) {
+            temp_storage_bytes = gs_lsb_copy_temp_bytes((uint64_t)num_items, pairs);
+            return hipSuccess;
+        }
+        return static_cast<hipError_t>(gs_lsb_sort_copy_u32(
+            d_temp_storage, temp_storage_bytes, reinterpret_cast<const uint32_t *>(d_keys_in),
+            reinterpret_cast<uint32_t *>(d_keys_out), reinterpret_cast<const uint32_t *>(d_values_in),
+            reinterpret_cast<uint32_t *>(d_values_out), (uint64_t)num_items, begin_bit, end_bit, descending ? 1 : 0,
+            KeyTraits<KeyT>::type, stream));
+    }
+    template <typename KeyT>
+    static hipError_t SortKeys(void *d_temp_storage, size_t &temp_storage_bytes, const KeyT *d_keys_in, KeyT *d_keys_out,
+                               int num_items, int begin_bit = 0, int end_bit = sizeof(KeyT) * 8, hipStream_t stream = 0,
+                               bool /*debug_synchronous*/ = false)
+    {
+        return DispatchCopy<KeyT, uint32_t>(d_temp_storage, temp_storage_bytes, d_keys_in, d_keys_out, nullptr, nullptr,
+                                            num_items, begin_bit, end_bit, false, stream);
+    }
+    template <typename KeyT, typename ValueT>
+    static hipError_t SortPairs(void *d_temp_storage, size_t &temp_storage_bytes, const KeyT *d_keys_in, KeyT *d_keys_out,
+                                const ValueT *d_values_in, ValueT *d_values_out, int num_items, int begin_bit = 0,
+                                int end_bit = sizeof(KeyT) * 8, hipStream_t stream = 0, bool /*debug_synchronous*/ = false)
+    {
+        static_assert(sizeof(ValueT) == 4, "32-bit values only");
+        return DispatchCopy<KeyT, ValueT>(d_temp_storage, temp_storage_bytes, d_keys_in, d_keys_out, d_values_in,
+                                          d_values_out, num_items, begin_bit, end_bit, false, stream);
+    }
+
     template <typename KeyT>
     static hipError_t SortKeys(void *d_temp_storage, size_t &temp_storage_bytes, DoubleBuffer<KeyT> &d_keys,
                                int num_items, int begin_bit = 0, int end_bit = sizeof(KeyT) * 8,

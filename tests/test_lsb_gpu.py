@@ -241,3 +241,29 @@ def test_device_generators_match_oracle(gs, cuda, oracle):
     inv, s, x = gs.check_sorted(to_dev(np.sort(k), cuda))
     assert inv == 0 and (s, x) == oracle.multiset_checksum(k)
     assert gs.check_sorted(to_dev(k, cuda))[0] == oracle.count_inversions_adjacent(k)
+
+
+@pytest.mark.parametrize("begin_bit,end_bit", [(0, 32), (0, 24), (5, 13), (9, 9)])
+@pytest.mark.parametrize("desc", [False, True])
+def test_no_overwrite_mode(gs, cuda, oracle, begin_bit, end_bit, desc):
+    """CUB_NO_OVERWRITE backend of test_device_radix_sort.cu (:798-804): input must be untouched."""
+    n = 123457
+    keys = oracle.cub_random_keys(n, 3)
+    vals = oracle.gen_enumerated(n)
+    kin, vin = to_dev(keys, cuda), to_dev(vals, cuda)
+    kout, vout = torch.empty_like(kin), torch.empty_like(vin)
+    nb = gs.DeviceRadixSort.SortPairsCopy(None, 0, kin, kout, vin, vout, n)
+    temp = torch.empty(nb, dtype=torch.uint8, device=cuda)
+    gs.DeviceRadixSort.SortPairsCopy(temp, nb, kin, kout, vin, vout, n, begin_bit, end_bit, key_type=gs.GS_KEY_U32,
+                                     descending=desc)
+    torch.cuda.synchronize()
+    ek, ev = oracle.lsb_sort_pairs(keys, vals, begin_bit, end_bit, desc)
+    assert np.array_equal(to_u32(kout), ek) and np.array_equal(to_u32(vout), ev)
+    assert np.array_equal(to_u32(kin), keys) and np.array_equal(to_u32(vin), vals)
+    kout2 = torch.empty_like(kin)
+    nb2 = gs.DeviceRadixSort.SortKeysCopy(None, 0, kin, kout2, n)
+    temp2 = torch.empty(nb2, dtype=torch.uint8, device=cuda)
+    gs.DeviceRadixSort.SortKeysCopy(temp2, nb2, kin, kout2, n, begin_bit, end_bit, key_type=gs.GS_KEY_U32, descending=desc)
+    torch.cuda.synchronize()
+    assert np.array_equal(to_u32(kout2), oracle.lsb_sort_keys(keys, begin_bit, end_bit, desc))
+    assert np.array_equal(to_u32(kin), keys)
