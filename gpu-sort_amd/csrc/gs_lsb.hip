@@ -25,6 +25,7 @@
 #include "gs_device.hpp"
 #include "gs_lsb.hpp"
 #include <cstdlib>
+#include <cstring>
 
 namespace gs {
 
@@ -83,6 +84,56 @@ __global__ __launch_bounds__(LSB_THREADS) void lsb_upsweep_kernel(const uint32_t
             run += hist[j][tid];
         }
         spine[(uint32_t)tid * p.grid + chunk] = run;
+    }
+}
+
+// ------------------------------------------------- single-sweep histogram --
+// Digit totals of ALL passes in one read of the keys (single-sweep mode): the digit of
+// pass q is taken from the twiddled key, which is what the later passes see.
+struct Hist4Params {
+    uint32_t n;
+    int num_passes;
+    uint32_t shift[4], bits[4];
+    int f32_in;
+    uint32_t xor_in;
+};
+template <bool VEC>
+__global__ __launch_bounds__(LSB_THREADS) void lsb_hist4_kernel(const uint32_t *__restrict__ keys,
+                                                                uint32_t *__restrict__ totals4, Hist4Params hp)
+{
+    __shared__ uint32_t h[LSB_WAVES][4][RADIX];
+    const int tid = threadIdx.x, w = wave_id();
+    for (int i = tid; i < LSB_WAVES * 4 * RADIX; i += LSB_THREADS) (&h[0][0][0])[i] = 0;
+    __syncthreads();
+    auto count = [&](uint32_t raw) {
+        const uint32_t k = twiddle_in(raw, hp.f32_in, hp.xor_in);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < hp.num_passes) hist_add(h[w][q], __builtin_amdgcn_ubfe(k, hp.shift[q], hp.bits[q]));
+    };
+    const uint32_t stride = gridDim.x * LSB_THREADS;
+    uint32_t done = 0;
+    if (VEC) {
+        const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+        const uint32_t nvec = hp.n >> 2;
+        uint32_t v = blockIdx.x * LSB_THREADS + tid;
+        for (; v + 3u * stride < nvec && v + 3u * stride >= v; v += 4u * stride) {
+            const uint4 a = k4[v], b = k4[v + stride], c = k4[v + 2 * stride], d = k4[v + 3 * stride];
+            count(a.x); count(a.y); count(a.z); count(a.w);
+            count(b.x); count(b.y); count(b.z); count(b.w);
+            count(c.x); count(c.y); count(c.z); count(c.w);
+            count(d.x); count(d.y); count(d.z); count(d.w);
+        }
+        for (; v < nvec; v += stride) { const uint4 a = k4[v]; count(a.x); count(a.y); count(a.z); count(a.w); }
+        done = nvec << 2;
+    }
+    for (uint64_t i = (uint64_t)done + blockIdx.x * LSB_THREADS + tid; i < hp.n; i += stride) count(keys[i]);
+    __syncthreads();
+    for (int i = tid; i < 4 * RADIX; i += LSB_THREADS) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int j = 0; j < LSB_WAVES; ++j) s += (&h[j][0][0])[i];
+        if (s) atomicAdd(&totals4[i], s);
     }
 }
 
@@ -168,11 +219,19 @@ __device__ __forceinline__ uint32_t tile_of_item(uint32_t i, uint32_t full_tiles
 // last in key order, its keys of digit d sit at the very end of digit d's global
 // range, so it needs only the digit totals.  Splitting it off keeps the guarded
 // path's registers out of the hot kernel.
-template <bool HAS_VALUES, bool TAIL>
+// FUSED = true (single-sweep mode, see the host section): no upsweep/scan ran for this pass;
+// the tile learns its global offsets by decoupled look-back over `status`, one 32-bit word
+// per (tile, digit): bits 31:30 = 0 empty / 1 tile count / 2 inclusive prefix, bits 29:0 the
+// value.  Each word is one self-validating granule written by one relaxed agent-scope store
+// and read by relaxed agent-scope loads (cdna_hip_programming.md Guideline 16, form R2).
+constexpr uint32_t ST_AGG = 1u << 30, ST_INC = 2u << 30, ST_VAL = (1u << 30) - 1u;
+
+template <bool HAS_VALUES, bool TAIL, bool FUSED = false>
 __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep_kernel(
     const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint16_t *__restrict__ prefix16,
-    const uint32_t *__restrict__ totals, PassParams p)
+    const uint32_t *__restrict__ totals, PassParams p, uint32_t *__restrict__ status = nullptr,
+    uint32_t *__restrict__ error_word = nullptr)
 {
     __shared__ __attribute__((aligned(16))) DownsweepSmem<HAS_VALUES> sm;
     constexpr bool ALLWAVE = HAS_VALUES;   // see step 3
@@ -243,7 +302,7 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
         }
         // this tile's global offsets (wave 0): scanned chunk count + count of the chunk's earlier tiles
         uint32_t tbase[4] = {0, 0, 0, 0};
-        if (!TAIL && w == 0) {
+        if (!TAIL && !FUSED && w == 0) {
             const uint32_t *sp = spine + (uint32_t)(4 * lane) * p.grid + t / LSB_CHUNK;
             const uint2 pf = reinterpret_cast<const uint2 *>(prefix16 + (size_t)t * RADIX)[lane];
             tbase[0] = sp[0] + (pf.x & 0xffffu);
@@ -254,6 +313,52 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
 
         // global base of digit run = digit start + tile offset - tile-local start (wave 0, lane l: digits 4l..4l+3)
         auto publish_gbase = [&](const uint32_t (&ex)[4], const uint32_t (&run)[4]) {
+            if (FUSED && !TAIL) {
+                // decoupled look-back (wave 0, lane l owns digits 4l..4l+3): publish this tile's
+                // counts, add up the predecessors' words walking backwards until an inclusive
+                // prefix is met, publish the own inclusive prefix.  Tiles are dispatched in order,
+                // so predecessors are resident or finished; every spin is bounded all the same.
+                uint32_t *mine = status + (size_t)t * RADIX + 4 * lane;
+                if (t == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) __hip_atomic_store(mine + q, ST_INC | run[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) __hip_atomic_store(mine + q, ST_AGG | run[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    uint32_t jq[4] = {t - 1, t - 1, t - 1, t - 1};
+                    bool done[4] = {false, false, false, false};
+                    uint32_t spins = 0;
+                    for (;;) {
+                        uint32_t e[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            e[q] = done[q] ? 0u
+                                           : __hip_atomic_load(status + (size_t)jq[q] * RADIX + 4 * lane + q, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT);
+                        bool waiting = false;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (done[q]) continue;
+                            const uint32_t f = e[q] >> 30;
+                            if (f == 0) { waiting = true; continue; }           // not published yet: retry
+                            tbase[q] += e[q] & ST_VAL;
+                            if (f == 2) done[q] = true; else --jq[q];             // tile 0 always publishes inclusive
+                        }
+                        const bool all_done = done[0] && done[1] && done[2] && done[3];
+                        if (__builtin_amdgcn_ballot_w64(!all_done) == 0) break;
+                        if (__builtin_amdgcn_ballot_w64(waiting) != 0) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > (1u << 22)) {                          // never hang the GPU
+                                if (lane == 0 && error_word) atomicOr(error_word, 1u);
+                                break;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        __hip_atomic_store(mine + q, ST_INC | ((tbase[q] + run[q]) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             uint32_t g[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) g[q] = dstart[q] + tbase[q] - ex[q];
@@ -438,8 +543,12 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline size_t spine_bytes(uint64_t n) { return align256((size_t)RADIX * lsb_grid(n) * sizeof(uint32_t)); }
 static inline size_t totals_bytes() { return align256(RADIX * sizeof(uint32_t)); }
 static inline size_t prefix16_bytes(uint64_t n) { return align256((size_t)lsb_num_tiles(n) * RADIX * sizeof(uint16_t)); }
+// single-sweep mode (n <= 2^30: 30-bit prefixes): digit totals of 4 passes + error word, and the look-back words
+static inline bool fused_possible(uint64_t n) { return n <= (1ull << 30) && n >= (uint64_t)LSB_TILE; }
+static inline size_t totals4_bytes() { return align256(4 * RADIX * sizeof(uint32_t)) + 256; }
+static inline size_t status_bytes(uint64_t n) { return fused_possible(n) ? align256((n / LSB_TILE) * RADIX * sizeof(uint32_t)) : 0; }
 
-size_t lsb_temp_bytes(uint64_t n) { return spine_bytes(n) + totals_bytes() + prefix16_bytes(n); }
+size_t lsb_temp_bytes(uint64_t n) { return spine_bytes(n) + totals_bytes() + prefix16_bytes(n) + totals4_bytes() + status_bytes(n); }
 LsbWorkspace lsb_carve(void *temp, uint64_t n)
 {
     char *c = (char *)temp;
@@ -447,6 +556,9 @@ LsbWorkspace lsb_carve(void *temp, uint64_t n)
     ws.spine = (uint32_t *)c;
     ws.totals = (uint32_t *)(c + spine_bytes(n));
     ws.prefix16 = (uint16_t *)(c + spine_bytes(n) + totals_bytes());
+    ws.totals4 = (uint32_t *)(c + spine_bytes(n) + totals_bytes() + prefix16_bytes(n));
+    ws.error_word = ws.totals4 + 4 * RADIX;
+    ws.status = fused_possible(n) ? (uint32_t *)((char *)ws.totals4 + totals4_bytes()) : nullptr;
     return ws;
 }
 
@@ -493,12 +605,25 @@ int lsb_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint
 }
 
 // shared pass loop: src/dst pointers per pass are chosen by `route`
+// LSB pass strategy.  "three" = upsweep -> scan -> downsweep per pass (the north_star's
+// formulation; 48 B/key for 4 passes).  "fused" = single-sweep: ONE histogram kernel gives the
+// digit totals of every pass, and each pass is a single scatter whose tiles get their offsets
+// by decoupled look-back (36 B/key); available for n <= 2^30.  Selected by GS_LSB_MODE
+// ("three" | "fused"); results are identical.
+static bool lsb_use_fused(uint64_t n)
+{
+    static const char *e = getenv("GS_LSB_MODE");
+    const bool want = e ? (strcmp(e, "fused") == 0) : false;
+    return want && fused_possible(n);
+}
+
 template <typename Route>
 static int lsb_run_passes(const LsbWorkspace &ws, uint64_t num_items, int begin_bit, int end_bit, int descending,
                           int key_type, bool pairs, hipStream_t s, Route route)
 {
     const int num_bits = end_bit - begin_bit;
     const int num_passes = (num_bits + RADIX_BITS - 1) / RADIX_BITS;
+    const bool fused = lsb_use_fused(num_items) && ws.status;
     for (int pass = 0; pass < num_passes; ++pass) {
         const int shift = begin_bit + pass * RADIX_BITS;
         const int bits = (end_bit - shift < RADIX_BITS) ? end_bit - shift : RADIX_BITS;
@@ -509,9 +634,52 @@ static int lsb_run_passes(const LsbWorkspace &ws, uint64_t num_items, int begin_
         route(pass, num_passes, kin, kout, vin, vout);
         if (!pairs) { vin = nullptr; vout = nullptr; }
         int e;
-        if ((e = lsb_upsweep(kin, ws.spine, ws.prefix16, p, s))) return e;
-        if ((e = lsb_scan(ws.spine, ws.totals, p.grid, s))) return e;
-        if ((e = lsb_downsweep(kin, kout, vin, vout, ws.spine, ws.prefix16, ws.totals, p, s))) return e;
+        if (!fused) {
+            if ((e = lsb_upsweep(kin, ws.spine, ws.prefix16, p, s))) return e;
+            if ((e = lsb_scan(ws.spine, ws.totals, p.grid, s))) return e;
+            if ((e = lsb_downsweep(kin, kout, vin, vout, ws.spine, ws.prefix16, ws.totals, p, s))) return e;
+            continue;
+        }
+        if (pass == 0) {   // digit totals of all passes from one read of the input
+            Hist4Params hp{};
+            hp.n = p.n; hp.num_passes = num_passes; hp.f32_in = p.f32_in; hp.xor_in = p.xor_in;
+            for (int q = 0; q < num_passes; ++q) {
+                hp.shift[q] = (uint32_t)(begin_bit + q * RADIX_BITS);
+                hp.bits[q] = (uint32_t)((end_bit - (int)hp.shift[q] < RADIX_BITS) ? end_bit - (int)hp.shift[q] : RADIX_BITS);
+            }
+            hipError_t me = hipMemsetAsync(ws.totals4, 0, totals4_bytes(), s);
+            if (me != hipSuccess) return (int)me;
+            KernelTimer kt(GS_K_LSB_UPSWEEP, s);
+            const uint32_t g = p.num_tiles < 2048u ? p.num_tiles : 2048u;
+            if (((uintptr_t)kin & 15u) == 0)
+                hipLaunchKernelGGL(lsb_hist4_kernel<true>, dim3(g), dim3(LSB_THREADS), 0, s, kin, ws.totals4, hp);
+            else
+                hipLaunchKernelGGL(lsb_hist4_kernel<false>, dim3(g), dim3(LSB_THREADS), 0, s, kin, ws.totals4, hp);
+        }
+        hipError_t me = hipMemsetAsync(ws.status, 0, status_bytes(num_items), s);
+        if (me != hipSuccess) return (int)me;
+        const uint32_t *tot = ws.totals4 + pass * RADIX;
+        {
+            KernelTimer kt(GS_K_LSB_DOWNSWEEP, s);
+            const dim3 block(LSB_THREADS);
+            if (vin)
+                hipLaunchKernelGGL((lsb_downsweep_kernel<true, false, true>), dim3(p.ds_grid), block, 0, s, kin, kout, vin,
+                                   vout, (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, ws.status, ws.error_word);
+            else
+                hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, true>), dim3(p.ds_grid), block, 0, s, kin, kout, vin,
+                                   vout, (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, ws.status, ws.error_word);
+            if (p.n % (uint32_t)LSB_TILE) {
+                if (vin)
+                    hipLaunchKernelGGL((lsb_downsweep_kernel<true, true>), dim3(1), block, 0, s, kin, kout, vin, vout,
+                                       (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, (uint32_t *)nullptr,
+                                       (uint32_t *)nullptr);
+                else
+                    hipLaunchKernelGGL((lsb_downsweep_kernel<false, true>), dim3(1), block, 0, s, kin, kout, vin, vout,
+                                       (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, (uint32_t *)nullptr,
+                                       (uint32_t *)nullptr);
+            }
+        }
+        if ((e = (int)hipGetLastError())) return e;
     }
     return hipSuccess;
 }

@@ -34,6 +34,9 @@ struct LsbWorkspace {
     uint32_t *spine;
     uint32_t *totals;
     uint16_t *prefix16;
+    uint32_t *totals4;      // single-sweep mode: digit totals of up to 4 passes
+    uint32_t *error_word;   // single-sweep mode: set if a bounded spin ever gave up
+    uint32_t *status;       // single-sweep mode: look-back words [full tiles][256]; nullptr if n > 2^30
 };
 
 size_t lsb_temp_bytes(uint64_t n);

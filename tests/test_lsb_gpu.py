@@ -267,3 +267,32 @@ def test_no_overwrite_mode(gs, cuda, oracle, begin_bit, end_bit, desc):
     torch.cuda.synchronize()
     assert np.array_equal(to_u32(kout2), oracle.lsb_sort_keys(keys, begin_bit, end_bit, desc))
     assert np.array_equal(to_u32(kin), keys)
+
+
+def test_single_sweep_mode_matches(cuda, oracle, tmp_path):
+    """GS_LSB_MODE=fused (one histogram kernel + look-back scatter per pass, experimental) is bit-exact too.
+    The mode is read once per process, so it runs in a child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import gpu_sort_amd as gs
+from oracle import oracle as O
+dev = torch.device("cuda:0")
+for n in (8192, 100003, (1 << 22) + 77):
+    keys = O.cub_random_keys(n, 3); vals = O.gen_enumerated(n)
+    for desc in (False, True):
+        dk = gs.DoubleBuffer(torch.from_numpy(keys.view(np.int32).copy()).to(dev), torch.empty(n, dtype=torch.int32, device=dev))
+        dv = gs.DoubleBuffer(torch.from_numpy(vals.view(np.int32).copy()).to(dev), torch.empty(n, dtype=torch.int32, device=dev))
+        fn = gs.DeviceRadixSort.SortPairsDescending if desc else gs.DeviceRadixSort.SortPairs
+        nb = fn(None, 0, dk, dv, n); temp = torch.zeros(nb, dtype=torch.uint8, device=dev)
+        fn(temp, nb, dk, dv, n, key_type=gs.GS_KEY_U32); torch.cuda.synchronize()
+        ek, ev = O.lsb_sort_pairs(keys, vals, descending=desc)
+        assert np.array_equal(dk.Current().cpu().numpy().view(np.uint32), ek)
+        assert np.array_equal(dv.Current().cpu().numpy().view(np.uint32), ev)
+print("fused ok")
+''' % root
+    env = dict(os.environ, GS_LSB_MODE="fused")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "fused ok" in out.stdout, out.stderr[-2000:]
