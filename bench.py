@@ -220,7 +220,8 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": (f"{algo}_radix_sort_2^{args.log2n}_u32_{args.dist}_"
                                     f"{'pairs' if args.pairs else 'keys_only'}" + ("_per_gpu_sharded" if sharded_path else "")),
-                       "keys_per_gpu": n, "has_values": args.pairs, "algorithm": algo,
+                       "keys_per_gpu": n, "has_values": args.pairs,
+                       "algorithm": (f"msb_bucket_shard+local_{args.algo or 'lsb'}" if sharded_path else algo),
                        "distribution": args.dist, "parallelism": "single" if not sharded_path else f"msb_bucket_shard{world}"},
             "roofline": roofline, "whole_sort": whole, "cpu_baseline": cpu,
             "kernels_ms_total": {k: [round(v[0], 3), v[1]] for k, v in kernels.items()},
