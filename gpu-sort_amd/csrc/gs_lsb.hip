@@ -544,7 +544,12 @@ static inline size_t spine_bytes(uint64_t n) { return align256((size_t)RADIX * l
 static inline size_t totals_bytes() { return align256(RADIX * sizeof(uint32_t)); }
 static inline size_t prefix16_bytes(uint64_t n) { return align256((size_t)lsb_num_tiles(n) * RADIX * sizeof(uint16_t)); }
 // single-sweep mode (n <= 2^30: 30-bit prefixes): digit totals of 4 passes + error word, and the look-back words
-static inline bool fused_possible(uint64_t n) { return n <= (1ull << 30) && n >= (uint64_t)LSB_TILE; }
+static inline bool fused_enabled()
+{
+    static const char *e = getenv("GS_LSB_MODE");   // read once per process: sizes and strategy stay consistent
+    return e && strcmp(e, "fused") == 0;
+}
+static inline bool fused_possible(uint64_t n) { return fused_enabled() && n <= (1ull << 30) && n >= (uint64_t)LSB_TILE; }
 static inline size_t totals4_bytes() { return align256(4 * RADIX * sizeof(uint32_t)) + 256; }
 static inline size_t status_bytes(uint64_t n) { return fused_possible(n) ? align256((n / LSB_TILE) * RADIX * sizeof(uint32_t)) : 0; }
 
@@ -610,12 +615,7 @@ int lsb_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint
 // digit totals of every pass, and each pass is a single scatter whose tiles get their offsets
 // by decoupled look-back (36 B/key); available for n <= 2^30.  Selected by GS_LSB_MODE
 // ("three" | "fused"); results are identical.
-static bool lsb_use_fused(uint64_t n)
-{
-    static const char *e = getenv("GS_LSB_MODE");
-    const bool want = e ? (strcmp(e, "fused") == 0) : false;
-    return want && fused_possible(n);
-}
+static bool lsb_use_fused(uint64_t n) { return fused_possible(n); }
 
 template <typename Route>
 static int lsb_run_passes(const LsbWorkspace &ws, uint64_t num_items, int begin_bit, int end_bit, int descending,
