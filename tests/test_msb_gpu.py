@@ -73,7 +73,7 @@ def test_sort_keys_numkeys_sweep(gs, cuda, oracle):
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4608, 4609, 6911, 6912, 6913,
-                               9216, 9217, 17408, 17409, 65539, (1 << 20) + 7, (1 << 24) + 1])
+                               9216, 9217, 16896, 16897, 17408, 17409, 65539, (1 << 20) + 7, (1 << 24) + 1])
 def test_sizes_keys_and_pairs(gs, cuda, oracle, n):
     keys = oracle.gen_uniform(n, seed=n)
     assert np.array_equal(_msb_keys(gs, keys, cuda), np.sort(keys))
