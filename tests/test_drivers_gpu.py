@@ -33,3 +33,16 @@ def test_msb_driver_output():
     out = _run(["msb_test", "20"])
     assert out[0].startswith("Time Sort K: ") and out[1].startswith("Time Sort KV: ")
     assert out[2].strip() == "Adjacent inversions in result: 0"
+
+
+def test_msb_harness_entropy_sweep():
+    """msb/tests counterpart: 12 entropy levels x repeats, gtest-style verdicts, profile table."""
+    out = _run(["msb_harness", "-r", "1", "-k", "150000", "-p", "80000", "--gtest_filter=Entropy_UINT"])
+    text = "\n".join(out)
+    assert "[       OK ] Sort_Keys.Entropy_UINT" in text and "FAILED" not in text
+    assert sum("SORTKEYS.ENTROPIES" in l for l in out) >= 12
+    rows = [l for l in out if l.startswith("sort_keys_UINT\t")]
+    assert len(rows) == 12 and all(len(r.split("\t")) == 8 for r in rows)
+    out = _run(["msb_harness", "-r", "1", "-p", "80000", "--gtest_filter=Sort_Pairs.UINT_UINT"])
+    text = "\n".join(out)
+    assert "[       OK ] Sort_Pairs.UINT_UINT" in text and "FAILED" not in text
