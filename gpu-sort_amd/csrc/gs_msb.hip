@@ -135,15 +135,28 @@ struct DigitSel {
     int f32_in;
     uint32_t xor_in;
 };
-__device__ __forceinline__ uint32_t digit_of(const DigitSel &ds, uint32_t k)
+constexpr int SHARD_MAX_BITS = 12;   // 4096 bins of the key space
+// `tab`: the remap table staged in LDS by load_remap (global gathers of a 4 KiB table cost more
+// than the rest of the kernel)
+__device__ __forceinline__ uint32_t digit_of(const DigitSel &ds, const uint8_t *tab, uint32_t k)
 {
-    if (ds.remap) return ds.remap[twiddle_in(k, ds.f32_in, ds.xor_in) >> ds.rshift];
+    if (ds.remap) return tab[twiddle_in(k, ds.f32_in, ds.xor_in) >> ds.rshift];
     return (k >> ds.shift) & 255u;
+}
+__device__ __forceinline__ void load_remap(const DigitSel &ds, uint8_t *tab)
+{
+    if (ds.remap) {
+        const uint32_t nb = 1u << (32 - ds.rshift);
+        for (uint32_t i = threadIdx.x; i < nb; i += blockDim.x) tab[i] = ds.remap[i];
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(MSB_THREADS) void msb_hist_kernel(MsbWs ws, int L, const uint32_t *__restrict__ src, DigitSel ds)
 {
     __shared__ uint32_t lh[MSB_WAVES][RADIX];
+    __shared__ uint8_t tab[1 << SHARD_MAX_BITS];
+    load_remap(ds, tab);
     const unsigned long long packed = ws.level[L].packed;
     const uint32_t nb = (uint32_t)(packed >> 32), ntiles = (uint32_t)packed;
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
@@ -165,12 +178,12 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_hist_kernel(MsbWs ws, int L, 
         const uint4 *p4 = reinterpret_cast<const uint4 *>(p + head);
         for (uint32_t v = (uint32_t)tid; v < nvec; v += MSB_THREADS) {
             const uint4 q = p4[v];
-            hist_add(my, digit_of(ds, q.x)); hist_add(my, digit_of(ds, q.y));
-            hist_add(my, digit_of(ds, q.z)); hist_add(my, digit_of(ds, q.w));
+            hist_add(my, digit_of(ds, tab, q.x)); hist_add(my, digit_of(ds, tab, q.y));
+            hist_add(my, digit_of(ds, tab, q.z)); hist_add(my, digit_of(ds, tab, q.w));
         }
-        if ((uint32_t)tid < head) hist_add(my, digit_of(ds, p[tid]));
+        if ((uint32_t)tid < head) hist_add(my, digit_of(ds, tab, p[tid]));
         const uint32_t tail0 = head + (nvec << 2);
-        if (tail0 + (uint32_t)tid < len) hist_add(my, digit_of(ds, p[tail0 + tid]));
+        if (tail0 + (uint32_t)tid < len) hist_add(my, digit_of(ds, tab, p[tail0 + tid]));
         __syncthreads();
         if (tid < RADIX) {
             uint32_t s = 0;
@@ -295,6 +308,8 @@ __global__ __launch_bounds__(MSB_THREADS, 4) void msb_scatter_kernel(MsbWs ws, i
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t lcnt[RADIX], lex[RADIX], gbase[RADIX];
     __shared__ uint32_t stage[MSB_TILE * (HAS_VALUES ? 2 : 1)];
+    __shared__ uint8_t tab[1 << SHARD_MAX_BITS];
+    load_remap(ds, tab);
     const unsigned long long packed = ws.level[L].packed;
     const uint32_t nb = (uint32_t)(packed >> 32), ntiles = (uint32_t)packed;
     const int tid = threadIdx.x;
@@ -319,7 +334,7 @@ __global__ __launch_bounds__(MSB_THREADS, 4) void msb_scatter_kernel(MsbWs ws, i
     for (int i = 0; i < MSB_KPT; ++i) {
         const uint32_t idx = (uint32_t)tid + i * MSB_THREADS;
         const bool ok = idx < valid;
-        const uint32_t d = digit_of(ds, key[i]);
+        const uint32_t d = digit_of(ds, tab, key[i]);
         // wave-aggregated rank: the lanes holding the same digit (ballot match) take consecutive
         // ranks from ONE fetch-add issued by the group's first lane, so a hot digit costs one LDS
         // atomic per wave instead of 64 colliding ones
@@ -349,7 +364,7 @@ __global__ __launch_bounds__(MSB_THREADS, 4) void msb_scatter_kernel(MsbWs ws, i
     for (int i = 0; i < MSB_KPT; ++i) {
         const uint32_t idx = (uint32_t)tid + i * MSB_THREADS;
         if (idx < valid) {
-            const uint32_t at = lex[digit_of(ds, key[i])] + rnk[i];
+            const uint32_t at = lex[digit_of(ds, tab, key[i])] + rnk[i];
             if (HAS_VALUES) reinterpret_cast<uint2 *>(stage)[at] = make_uint2(key[i], val[i]);
             else stage[at] = key[i];
         }
@@ -366,7 +381,7 @@ __global__ __launch_bounds__(MSB_THREADS, 4) void msb_scatter_kernel(MsbWs ws, i
             } else {
                 k = stage[slot];
             }
-            const uint32_t dst = gbase[digit_of(ds, k)] + slot;
+            const uint32_t dst = gbase[digit_of(ds, tab, k)] + slot;
             dst_k[dst] = twiddle_out(k, f32_out, xor_out);
             if (HAS_VALUES) dst_v[dst] = v;
         }
@@ -503,7 +518,6 @@ __global__ __launch_bounds__(MSB_THREADS, 4) void msb_local_sort_kernel(MsbWs ws
 }
 
 // ------------------------------------------------------------------ shard --
-constexpr int SHARD_MAX_BITS = 12;   // 4096 bins of the key space: 16 KiB of LDS counters
 
 // 2^bits-bin histogram of the keys' top bits (after the order-preserving twiddle), u64 counts
 template <bool VEC>
@@ -730,7 +744,7 @@ int gs_shard_partition_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_ke
     lsb_twiddle_masks(key_type, 0, true, true, tw);
     const DigitSel dsel{0, d_dest_of_bin, 32 - bits, tw.f32_in, tw.xor_in};
     const uint32_t tiles = (n + MSB_TILE - 1) / MSB_TILE;
-    const uint32_t grid = tiles < MSB_MAX_GRID ? tiles : MSB_MAX_GRID;
+    const uint32_t grid = tiles;   // the tile count is known here: one tile per block, dispatched in order
     KernelTimer kt(GS_K_SHARD, s);
     // one bucket = the whole shard, "digit" = destination rank: counts -> cursors -> unstable scatter
     hipLaunchKernelGGL(msb_init_kernel, dim3(1), dim3(64), 0, s, ws, n);
