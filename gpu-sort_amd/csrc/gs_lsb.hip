@@ -226,7 +226,7 @@ __device__ __forceinline__ uint32_t tile_of_item(uint32_t i, uint32_t full_tiles
 // and read by relaxed agent-scope loads (cdna_hip_programming.md Guideline 16, form R2).
 constexpr uint32_t ST_AGG = 1u << 30, ST_INC = 2u << 30, ST_VAL = (1u << 30) - 1u;
 
-template <bool HAS_VALUES, bool TAIL, bool FUSED = false>
+template <bool HAS_VALUES, bool TAIL, bool FUSED = false, bool F32 = false>
 __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep_kernel(
     const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint16_t *__restrict__ prefix16,
@@ -235,6 +235,7 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
 {
     __shared__ __attribute__((aligned(16))) DownsweepSmem<HAS_VALUES> sm;
     constexpr bool ALLWAVE = HAS_VALUES;   // see step 3
+    // F32 = false: the float twiddle is compiled out (u32 / i32 keys and every middle pass)
 
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const uint32_t full_tiles = p.n / (uint32_t)LSB_TILE;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
         } else {
             // pad with keys whose twiddled form is all ones (largest digit; ranked after
             // every real key of that digit because they sit at the tail)
-            const uint32_t pad = twiddle_out(0xffffffffu, p.f32_in, p.xor_in);
+            const uint32_t pad = twiddle_out(0xffffffffu, (F32 ? p.f32_in : 0), p.xor_in);
 #pragma unroll
             for (int i = 0; i < LSB_KPT; ++i) {
                 const uint32_t idx = wbase + i * WAVE;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
 
         uint32_t key[LSB_KPT], val[LSB_KPT], pos[LSB_KPT];
 #pragma unroll
-        for (int i = 0; i < LSB_KPT; ++i) key[i] = twiddle_in(knext[i], p.f32_in, p.xor_in);
+        for (int i = 0; i < LSB_KPT; ++i) key[i] = twiddle_in(knext[i], (F32 ? p.f32_in : 0), p.xor_in);
         if (HAS_VALUES) {
             const uint32_t *vin = vals_in + tile_base;
 #pragma unroll
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
             }
             const uint32_t dst = sm.gbase[__builtin_amdgcn_ubfe(k, p.shift, p.bits)] + slot;
             if (!TAIL || slot < valid) {
-                keys_out[dst] = twiddle_out(k, p.f32_out, p.xor_out);
+                keys_out[dst] = twiddle_out(k, (F32 ? p.f32_out : 0), p.xor_out);
                 if (HAS_VALUES) vals_out[dst] = v;
             }
         }
@@ -585,31 +586,38 @@ int lsb_scan(uint32_t *spine, uint32_t *totals, uint32_t grid, hipStream_t s)
     return (int)hipGetLastError();
 }
 
+template <bool F32>
+static void launch_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, const uint32_t *spine,
+                             const uint16_t *prefix16, const uint32_t *totals, const PassParams &p, hipStream_t s)
+{
+    const dim3 block(LSB_THREADS);
+    if (p.n >= (uint32_t)LSB_TILE) {   // full tiles
+        if (vin)
+            hipLaunchKernelGGL((lsb_downsweep_kernel<true, false, false, F32>), dim3(p.ds_grid), block, 0, s, kin, kout, vin,
+                               vout, spine, prefix16, totals, p, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        else
+            hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, false, F32>), dim3(p.ds_grid), block, 0, s, kin, kout,
+                               vin, vout, spine, prefix16, totals, p, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    }
+    if (p.n % (uint32_t)LSB_TILE) {    // the partial last tile, if any
+        if (vin)
+            hipLaunchKernelGGL((lsb_downsweep_kernel<true, true, false, F32>), dim3(1), block, 0, s, kin, kout, vin, vout,
+                               spine, prefix16, totals, p, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        else
+            hipLaunchKernelGGL((lsb_downsweep_kernel<false, true, false, F32>), dim3(1), block, 0, s, kin, kout, vin, vout,
+                               spine, prefix16, totals, p, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    }
+}
+
 int lsb_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, const uint32_t *spine,
                   const uint16_t *prefix16, const uint32_t *totals, const PassParams &p, hipStream_t s)
 {
     KernelTimer kt(GS_K_LSB_DOWNSWEEP, s);
-    const dim3 block(LSB_THREADS);
-    if (p.n >= (uint32_t)LSB_TILE) {   // full tiles
-        if (vin)
-            hipLaunchKernelGGL((lsb_downsweep_kernel<true, false>), dim3(p.ds_grid), block, 0, s, kin, kout, vin, vout,
-                               spine, prefix16, totals, p);
-        else
-            hipLaunchKernelGGL((lsb_downsweep_kernel<false, false>), dim3(p.ds_grid), block, 0, s, kin, kout, vin,
-                               vout, spine, prefix16, totals, p);
-    }
-    if (p.n % (uint32_t)LSB_TILE) {    // the partial last tile, if any
-        if (vin)
-            hipLaunchKernelGGL((lsb_downsweep_kernel<true, true>), dim3(1), block, 0, s, kin, kout, vin, vout, spine,
-                               prefix16, totals, p);
-        else
-            hipLaunchKernelGGL((lsb_downsweep_kernel<false, true>), dim3(1), block, 0, s, kin, kout, vin, vout, spine,
-                               prefix16, totals, p);
-    }
+    if (p.f32_in || p.f32_out) launch_downsweep<true>(kin, kout, vin, vout, spine, prefix16, totals, p, s);
+    else launch_downsweep<false>(kin, kout, vin, vout, spine, prefix16, totals, p, s);
     return (int)hipGetLastError();
 }
 
-// shared pass loop: src/dst pointers per pass are chosen by `route`
 // LSB pass strategy.  "three" = upsweep -> scan -> downsweep per pass (the north_star's
 // formulation; 48 B/key for 4 passes).  "fused" = single-sweep: ONE histogram kernel gives the
 // digit totals of every pass, and each pass is a single scatter whose tiles get their offsets
@@ -663,18 +671,18 @@ static int lsb_run_passes(const LsbWorkspace &ws, uint64_t num_items, int begin_
             KernelTimer kt(GS_K_LSB_DOWNSWEEP, s);
             const dim3 block(LSB_THREADS);
             if (vin)
-                hipLaunchKernelGGL((lsb_downsweep_kernel<true, false, true>), dim3(p.ds_grid), block, 0, s, kin, kout, vin,
+                hipLaunchKernelGGL((lsb_downsweep_kernel<true, false, true, true>), dim3(p.ds_grid), block, 0, s, kin, kout, vin,
                                    vout, (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, ws.status, ws.error_word);
             else
-                hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, true>), dim3(p.ds_grid), block, 0, s, kin, kout, vin,
+                hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, true, true>), dim3(p.ds_grid), block, 0, s, kin, kout, vin,
                                    vout, (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, ws.status, ws.error_word);
             if (p.n % (uint32_t)LSB_TILE) {
                 if (vin)
-                    hipLaunchKernelGGL((lsb_downsweep_kernel<true, true>), dim3(1), block, 0, s, kin, kout, vin, vout,
+                    hipLaunchKernelGGL((lsb_downsweep_kernel<true, true, false, true>), dim3(1), block, 0, s, kin, kout, vin, vout,
                                        (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, (uint32_t *)nullptr,
                                        (uint32_t *)nullptr);
                 else
-                    hipLaunchKernelGGL((lsb_downsweep_kernel<false, true>), dim3(1), block, 0, s, kin, kout, vin, vout,
+                    hipLaunchKernelGGL((lsb_downsweep_kernel<false, true, false, true>), dim3(1), block, 0, s, kin, kout, vin, vout,
                                        (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, (uint32_t *)nullptr,
                                        (uint32_t *)nullptr);
             }
