@@ -1,0 +1,296 @@
+// gs_wide.hip -- the LSB three-kernel pass for the wider element types of the
+// DeviceRadixSort contract (lsb/cub/test/test_device_radix_sort.cu
+// :934-943,1244-1265): 64-bit keys (unsigned, signed, double) with no / 32-bit / 64-bit
+// values, and 32-bit keys with 64-bit values.  The graded u32 / (u32,u32) configurations
+// stay on the tuned kernels of gs_lsb.hip; this file trades some speed for generality:
+//   - tiles of 4096 keys, 8 keys per thread, one tile per block in dispatch order;
+//   - the same decomposition (spine per chunk of 8 tiles + u16 in-chunk prefixes), the
+//     same wave64 ballot/popcount ranking and LDS staging;
+//   - keys and values go through ONE staging buffer one after the other (a tile of
+//     64-bit keys fills it), and partial tiles are handled in place with guarded loads.
+#include "gs_device.hpp"
+#include "gs_lsb.hpp"
+#include <type_traits>
+
+namespace gs {
+
+constexpr int W_THREADS = 512;
+constexpr int W_WAVES = W_THREADS / WAVE;
+constexpr int W_KPT = 8;
+constexpr int W_TILE = W_THREADS * W_KPT;   // 4096 elements
+constexpr int W_CHUNK = W_WAVES;            // tiles per chunk (one wave per tile in the upsweep)
+
+struct NoVal {};
+
+struct WideParams {
+    uint64_t n;
+    uint32_t num_tiles, grid;       // grid = chunks
+    uint32_t shift, bits, mask;
+    int f_in, f_out;                // float twiddle on read / undo on write
+    uint64_t xor_in, xor_out;       // sign flip and descending complement
+};
+
+template <typename K> __device__ __forceinline__ K w_twiddle_in(K k, int f, uint64_t x);
+template <typename K> __device__ __forceinline__ K w_twiddle_out(K k, int f, uint64_t x);
+template <> __device__ __forceinline__ uint32_t w_twiddle_in<uint32_t>(uint32_t k, int f, uint64_t x) { return twiddle_in(k, f, (uint32_t)x); }
+template <> __device__ __forceinline__ uint32_t w_twiddle_out<uint32_t>(uint32_t k, int f, uint64_t x) { return twiddle_out(k, f, (uint32_t)x); }
+// lsb/cub/cub/util_type.cuh:1079-1089 for 64-bit: negative -> flip all bits, else flip the sign bit
+template <> __device__ __forceinline__ uint64_t w_twiddle_in<uint64_t>(uint64_t k, int f, uint64_t x)
+{
+    if (f) k ^= (uint64_t)((int64_t)k >> 63) | 0x8000000000000000ull;
+    return k ^ x;
+}
+template <> __device__ __forceinline__ uint64_t w_twiddle_out<uint64_t>(uint64_t k, int f, uint64_t x)
+{
+    k ^= x;
+    if (f) k ^= ~(uint64_t)((int64_t)k >> 63) | 0x8000000000000000ull;
+    return k;
+}
+template <typename K> __device__ __forceinline__ uint32_t w_digit(K k, const WideParams &p) { return (uint32_t)(k >> p.shift) & p.mask; }
+
+// ---------------------------------------------------------------- upsweep --
+template <typename K>
+__global__ __launch_bounds__(W_THREADS) void wide_upsweep_kernel(const K *__restrict__ keys, uint32_t *__restrict__ spine,
+                                                                 uint16_t *__restrict__ prefix16, WideParams p)
+{
+    __shared__ uint32_t hist[W_WAVES][RADIX];
+    const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    uint32_t *my = hist[w];
+#pragma unroll
+    for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
+    const uint32_t chunk = blockIdx.x;
+    const uint32_t tile = chunk * W_CHUNK + (uint32_t)w;
+    if (tile < p.num_tiles) {
+        const uint64_t lo = (uint64_t)tile * W_TILE;
+        const uint32_t len = (p.n - lo < (uint64_t)W_TILE) ? (uint32_t)(p.n - lo) : (uint32_t)W_TILE;
+        const K *src = keys + lo;
+        for (uint32_t i = lane; i < len; i += WAVE) hist_add(my, w_digit(w_twiddle_in<K>(src[i], p.f_in, p.xor_in), p));
+    }
+    __syncthreads();
+    if (tid < RADIX) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int j = 0; j < W_WAVES; ++j) {
+            const uint32_t t = chunk * W_CHUNK + (uint32_t)j;
+            if (t < p.num_tiles) prefix16[(size_t)t * RADIX + tid] = (uint16_t)run;
+            run += hist[j][tid];
+        }
+        spine[(uint32_t)tid * p.grid + chunk] = run;
+    }
+}
+
+// the spine scan is gs_lsb.hip's (same layout)
+int lsb_scan(uint32_t *spine, uint32_t *totals, uint32_t grid, hipStream_t s);
+
+// -------------------------------------------------------------- downsweep --
+template <typename K, typename V>
+__global__ __launch_bounds__(W_THREADS, 4) void wide_downsweep_kernel(const K *__restrict__ keys_in, K *__restrict__ keys_out,
+                                                                     const V *__restrict__ vals_in, V *__restrict__ vals_out,
+                                                                     const uint32_t *__restrict__ spine,
+                                                                     const uint16_t *__restrict__ prefix16,
+                                                                     const uint32_t *__restrict__ totals, WideParams p)
+{
+    constexpr bool HAS_VALUES = !std::is_same<V, NoVal>::value;
+    constexpr size_t ELEM = sizeof(K) > (HAS_VALUES ? sizeof(V) : 1) ? sizeof(K) : sizeof(V);
+    __shared__ uint32_t whist[W_WAVES][RADIX];
+    __shared__ uint32_t gbase[RADIX];
+    __shared__ __attribute__((aligned(16))) unsigned char stage_raw[W_TILE * ELEM];
+    K *stage_k = reinterpret_cast<K *>(stage_raw);
+
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const uint32_t t = blockIdx.x;
+    const uint64_t tile_base = (uint64_t)t * W_TILE;
+    const uint32_t valid = (p.n - tile_base < (uint64_t)W_TILE) ? (uint32_t)(p.n - tile_base) : (uint32_t)W_TILE;
+    uint32_t *my = whist[w];
+    const uint32_t wbase = (uint32_t)w * (WAVE * W_KPT) + lane;
+
+    // wave 0, lane l: global start of digits 4l..4l+3 and this tile's offset inside them
+    uint32_t g0[4] = {0, 0, 0, 0};
+    if (w == 0) {
+        const uint4 tot = reinterpret_cast<const uint4 *>(totals)[lane];
+        const uint32_t lane_sum = tot.x + tot.y + tot.z + tot.w;
+        const uint32_t ex = wave_inclusive_scan(lane_sum) - lane_sum;
+        const uint32_t *sp = spine + (uint32_t)(4 * lane) * p.grid + t / W_CHUNK;
+        const uint2 pf = reinterpret_cast<const uint2 *>(prefix16 + (size_t)t * RADIX)[lane];
+        g0[0] = ex + sp[0] + (pf.x & 0xffffu);
+        g0[1] = ex + tot.x + sp[p.grid] + (pf.x >> 16);
+        g0[2] = ex + tot.x + tot.y + sp[2 * p.grid] + (pf.y & 0xffffu);
+        g0[3] = ex + tot.x + tot.y + tot.z + sp[3 * p.grid] + (pf.y >> 16);
+    }
+
+    K key[W_KPT];
+    uint32_t pos[W_KPT];
+    const K pad = (K)~(K)0;                     // twiddled all-ones: largest digit, ranked last
+#pragma unroll
+    for (int i = 0; i < W_KPT; ++i) {
+        const uint32_t idx = wbase + i * WAVE;
+        key[i] = (idx < valid) ? w_twiddle_in<K>(keys_in[tile_base + idx], p.f_in, p.xor_in) : pad;
+    }
+#pragma unroll
+    for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
+#pragma unroll
+    for (int i = 0; i < W_KPT; ++i) {
+        const uint32_t d = w_digit(key[i], p);
+        uint32_t plo, phi;
+        match_digit(d, plo, phi);
+        const uint32_t lower = count_lower(plo, phi);
+        pos[i] = my[d] + lower;
+        if (lower == 0)
+            __hip_atomic_fetch_add(&my[d], (uint32_t)(__popc(plo) + __popc(phi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+#pragma unroll
+    for (int i = 0; i < W_KPT; ++i) asm volatile("" : "+v"(pos[i]));
+    __syncthreads();
+    if (w == 0) {
+        uint32_t run[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < W_WAVES; ++j) {
+            const uint4 x = reinterpret_cast<const uint4 *>(whist[j])[lane];
+            run[0] += x.x; run[1] += x.y; run[2] += x.z; run[3] += x.w;
+        }
+        const uint32_t lane_sum = run[0] + run[1] + run[2] + run[3];
+        uint4 e4;
+        e4.x = wave_inclusive_scan(lane_sum) - lane_sum;
+        e4.y = e4.x + run[0];
+        e4.z = e4.y + run[1];
+        e4.w = e4.z + run[2];
+        reinterpret_cast<uint4 *>(gbase)[lane] = make_uint4(g0[0] - e4.x, g0[1] - e4.y, g0[2] - e4.z, g0[3] - e4.w);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < W_WAVES; ++j) {
+            const uint4 x = reinterpret_cast<const uint4 *>(whist[j])[lane];
+            reinterpret_cast<uint4 *>(whist[j])[lane] = e4;
+            e4.x += x.x; e4.y += x.y; e4.z += x.z; e4.w += x.w;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < W_KPT; ++i) {
+        pos[i] += my[w_digit(key[i], p)];
+        stage_k[pos[i]] = key[i];
+    }
+    __syncthreads();
+    uint32_t dst[W_KPT];
+#pragma unroll
+    for (int i = 0; i < W_KPT; ++i) {
+        const uint32_t slot = (uint32_t)tid + i * W_THREADS;
+        const K k = stage_k[slot];
+        dst[i] = gbase[w_digit(k, p)] + slot;
+        if (slot < valid) keys_out[dst[i]] = w_twiddle_out<K>(k, p.f_out, p.xor_out);
+    }
+    if constexpr (HAS_VALUES) {
+        V *stage_v = reinterpret_cast<V *>(stage_raw);
+        V val[W_KPT];
+#pragma unroll
+        for (int i = 0; i < W_KPT; ++i) {
+            const uint32_t idx = wbase + i * WAVE;
+            val[i] = (idx < valid) ? vals_in[tile_base + idx] : V(0);
+        }
+        __syncthreads();                       // everyone is done reading the keys
+#pragma unroll
+        for (int i = 0; i < W_KPT; ++i) stage_v[pos[i]] = val[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < W_KPT; ++i) {
+            const uint32_t slot = (uint32_t)tid + i * W_THREADS;
+            if (slot < valid) vals_out[dst[i]] = stage_v[slot];
+        }
+    }
+}
+
+// ------------------------------------------------------------------- host --
+static inline size_t w_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline uint32_t w_tiles(uint64_t n) { return (uint32_t)((n + W_TILE - 1) / W_TILE); }
+static inline uint32_t w_grid(uint64_t n) { const uint32_t t = w_tiles(n); return t ? (t + W_CHUNK - 1) / W_CHUNK : 1u; }
+static inline size_t w_spine_bytes(uint64_t n) { return w_align256((size_t)RADIX * w_grid(n) * 4); }
+static inline size_t w_totals_bytes() { return w_align256(RADIX * 4); }
+static inline size_t w_prefix_bytes(uint64_t n) { return w_align256((size_t)(w_tiles(n) ? w_tiles(n) : 1) * RADIX * 2); }
+
+template <typename K, typename V>
+static int wide_pass(const K *kin, K *kout, const V *vin, V *vout, uint32_t *spine, uint32_t *totals, uint16_t *prefix16,
+                     const WideParams &p, hipStream_t s)
+{
+    { KernelTimer kt(GS_K_LSB_UPSWEEP, s);
+      hipLaunchKernelGGL(wide_upsweep_kernel<K>, dim3(p.grid), dim3(W_THREADS), 0, s, kin, spine, prefix16, p); }
+    int e = lsb_scan(spine, totals, p.grid, s);
+    if (e) return e;
+    { KernelTimer kt(GS_K_LSB_DOWNSWEEP, s);
+      hipLaunchKernelGGL((wide_downsweep_kernel<K, V>), dim3(p.num_tiles), dim3(W_THREADS), 0, s, kin, kout, vin, vout,
+                         (const uint32_t *)spine, (const uint16_t *)prefix16, (const uint32_t *)totals, p); }
+    return (int)hipGetLastError();
+}
+
+template <typename K, typename V>
+static int wide_sort(void *d_temp, void *d_keys[2], void *d_vals[2], int *selector, uint64_t n, int begin_bit, int end_bit,
+                     int descending, int key_type, hipStream_t s)
+{
+    char *c = (char *)d_temp;
+    uint32_t *spine = (uint32_t *)c;
+    uint32_t *totals = (uint32_t *)(c + w_spine_bytes(n));
+    uint16_t *prefix16 = (uint16_t *)(c + w_spine_bytes(n) + w_totals_bytes());
+    const int num_passes = (end_bit - begin_bit + RADIX_BITS - 1) / RADIX_BITS;
+    const bool is_float = key_type == GS_KEY_F32 || key_type == GS_KEY_F64;
+    const bool is_signed = key_type == GS_KEY_I32 || key_type == GS_KEY_I64;
+    const uint64_t sign = is_signed ? (sizeof(K) == 8 ? 0x8000000000000000ull : 0x80000000ull) : 0ull;
+    const uint64_t flip = descending ? ~0ull : 0ull;
+    int sel = *selector;
+    for (int pass = 0; pass < num_passes; ++pass) {
+        WideParams p{};
+        p.n = n; p.num_tiles = w_tiles(n); p.grid = w_grid(n);
+        p.shift = (uint32_t)(begin_bit + pass * RADIX_BITS);
+        p.bits = (uint32_t)((end_bit - (int)p.shift < RADIX_BITS) ? end_bit - (int)p.shift : RADIX_BITS);
+        p.mask = (1u << p.bits) - 1u;
+        const bool first = pass == 0, last = pass == num_passes - 1;
+        p.f_in = (first && is_float) ? 1 : 0;
+        p.f_out = (last && is_float) ? 1 : 0;
+        p.xor_in = first ? (sign ^ flip) : 0ull;
+        p.xor_out = last ? (sign ^ flip) : 0ull;
+        const int e = wide_pass<K, V>((const K *)d_keys[sel], (K *)d_keys[sel ^ 1], d_vals ? (const V *)d_vals[sel] : nullptr,
+                                      d_vals ? (V *)d_vals[sel ^ 1] : nullptr, spine, totals, prefix16, p, s);
+        if (e) return e;
+        sel ^= 1;
+    }
+    *selector = sel;
+    return hipSuccess;
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" {
+
+size_t gs_lsb_wide_temp_bytes(uint64_t num_items, int /*key_bytes*/, int /*val_bytes*/)
+{
+    return w_spine_bytes(num_items) + w_totals_bytes() + w_prefix_bytes(num_items);
+}
+
+int gs_lsb_sort_wide(void *d_temp, size_t temp_bytes, void *d_keys[2], void *d_vals[2], int *selector, uint64_t num_items,
+                     int key_bytes, int val_bytes, int begin_bit, int end_bit, int descending, int key_type, void *stream)
+{
+    if (!selector || (*selector != 0 && *selector != 1) || !d_keys) return hipErrorInvalidValue;
+    if (key_bytes != 4 && key_bytes != 8) return hipErrorInvalidValue;
+    if (val_bytes != 0 && val_bytes != 4 && val_bytes != 8) return hipErrorInvalidValue;
+    if ((val_bytes != 0) != (d_vals != nullptr)) return hipErrorInvalidValue;
+    if (begin_bit < 0 || end_bit > 8 * key_bytes || begin_bit > end_bit) return hipErrorInvalidValue;
+    if (num_items >= (1ull << 32)) return hipErrorInvalidValue;
+    const bool k64 = key_bytes == 8;
+    if (k64 ? (key_type < GS_KEY_U64 || key_type > GS_KEY_F64) : (key_type < GS_KEY_U32 || key_type > GS_KEY_F32))
+        return hipErrorInvalidValue;
+    if (num_items == 0 || begin_bit == end_bit) return hipSuccess;
+    if (!d_temp || temp_bytes < gs_lsb_wide_temp_bytes(num_items, key_bytes, val_bytes)) return hipErrorInvalidValue;
+    if (!d_keys[0] || !d_keys[1] || (d_vals && (!d_vals[0] || !d_vals[1]))) return hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+#define GS_WIDE(K, V) return wide_sort<K, V>(d_temp, d_keys, d_vals, selector, num_items, begin_bit, end_bit, descending, key_type, s)
+    if (k64) {
+        if (val_bytes == 0) GS_WIDE(uint64_t, NoVal);
+        if (val_bytes == 4) GS_WIDE(uint64_t, uint32_t);
+        GS_WIDE(uint64_t, uint64_t);
+    }
+    if (val_bytes == 0) GS_WIDE(uint32_t, NoVal);
+    if (val_bytes == 4) GS_WIDE(uint32_t, uint32_t);
+    GS_WIDE(uint32_t, uint64_t);
+#undef GS_WIDE
+}
+
+}  // extern "C"

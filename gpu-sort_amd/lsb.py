@@ -12,9 +12,12 @@ import torch
 from . import _lib
 from ._lib import lib, check
 
-_KEY_TYPES = {torch.int32: _lib.GS_KEY_I32, torch.float32: _lib.GS_KEY_F32}
+_KEY_TYPES = {torch.int32: _lib.GS_KEY_I32, torch.float32: _lib.GS_KEY_F32,
+              torch.int64: _lib.GS_KEY_I64, torch.float64: _lib.GS_KEY_F64}
 if hasattr(torch, "uint32"):
     _KEY_TYPES[torch.uint32] = _lib.GS_KEY_U32
+if hasattr(torch, "uint64"):
+    _KEY_TYPES[torch.uint64] = _lib.GS_KEY_U64
 
 
 def _stream_ptr(stream):
@@ -23,11 +26,11 @@ def _stream_ptr(stream):
     return C.c_void_p(stream.cuda_stream)
 
 
-def _check_buf(t, n, what):
+def _check_buf(t, n, what, elem=4):
     if not isinstance(t, torch.Tensor) or not t.is_cuda or not t.is_contiguous():
         raise ValueError(f"{what}: expected a contiguous device tensor")
-    if t.element_size() != 4 or t.numel() < n:
-        raise ValueError(f"{what}: need >= {n} 4-byte elements")
+    if t.element_size() != elem or t.numel() < n:
+        raise ValueError(f"{what}: need >= {n} {elem}-byte elements")
 
 
 class DoubleBuffer:
@@ -51,6 +54,11 @@ class DeviceRadixSort:
     def _sort(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, begin_bit, end_bit, descending,
               stream, key_type):
         has_values = d_values is not None
+        kb = d_keys.d_buffers[0].element_size()
+        vb = d_values.d_buffers[0].element_size() if has_values else 0
+        if kb == 8 or vb == 8:
+            return DeviceRadixSort._sort_wide(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, begin_bit,
+                                              end_bit, descending, stream, key_type, kb, vb)
         need = lib.gs_lsb_temp_bytes(num_items, int(has_values))
         if d_temp_storage is None:                      # dispatch_radix_sort.cuh:1110
             return need
@@ -75,6 +83,36 @@ class DeviceRadixSort:
         check(err, "gs_lsb_sort_u32")
         d_keys.selector = sel.value
         if has_values:
+            d_values.selector = sel.value
+        return need
+
+    @staticmethod
+    def _sort_wide(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, begin_bit, end_bit, descending,
+                   stream, key_type, kb, vb):
+        """64-bit keys and/or 64-bit values: the general kernels behind gs_lsb_sort_wide."""
+        need = lib.gs_lsb_wide_temp_bytes(num_items, kb, vb)
+        if d_temp_storage is None:
+            return need
+        if end_bit is None:
+            end_bit = 8 * kb
+        if key_type is None:
+            key_type = _KEY_TYPES.get(d_keys.d_buffers[0].dtype, _lib.GS_KEY_U64 if kb == 8 else _lib.GS_KEY_U32)
+        for b in d_keys.d_buffers:
+            _check_buf(b, num_items, "d_keys", kb)
+        keys = (C.c_void_p * 2)(d_keys.d_buffers[0].data_ptr(), d_keys.d_buffers[1].data_ptr())
+        vals = None
+        if vb:
+            for b in d_values.d_buffers:
+                _check_buf(b, num_items, "d_values", vb)
+            vals = (C.c_void_p * 2)(d_values.d_buffers[0].data_ptr(), d_values.d_buffers[1].data_ptr())
+        sel = C.c_int(d_keys.selector)
+        err = lib.gs_lsb_sort_wide(C.c_void_p(d_temp_storage.data_ptr()),
+                                   min(temp_storage_bytes, d_temp_storage.numel() * d_temp_storage.element_size()),
+                                   keys, vals, C.byref(sel), num_items, kb, vb, begin_bit, end_bit, int(descending),
+                                   key_type, _stream_ptr(stream))
+        check(err, "gs_lsb_sort_wide")
+        d_keys.selector = sel.value
+        if vb:
             d_values.selector = sel.value
         return need
 

@@ -36,7 +36,10 @@ extern "C" {
 enum gs_key_type {
     GS_KEY_U32 = 0,   /* identity                                  */
     GS_KEY_I32 = 1,   /* flip the sign bit                         */
-    GS_KEY_F32 = 2    /* negative: flip all bits; else flip sign   */
+    GS_KEY_F32 = 2,   /* negative: flip all bits; else flip sign   */
+    GS_KEY_U64 = 3,   /* 64-bit keys: gs_lsb_sort_wide only        */
+    GS_KEY_I64 = 4,
+    GS_KEY_F64 = 5
 };
 
 int         gs_version(void);
@@ -79,6 +82,18 @@ int gs_lsb_sort_copy_u32(void *d_temp, size_t temp_bytes,
                          const uint32_t *d_vals_in, uint32_t *d_vals_out,
                          uint64_t num_items, int begin_bit, int end_bit,
                          int descending, int key_type, void *stream);
+
+/* Wider element types of the DeviceRadixSort contract
+ * (lsb/cub/test/test_device_radix_sort.cu:934-943,1244-1265): keys of
+ * key_bytes = 4 or 8 (GS_KEY_U32..F32 / GS_KEY_U64..F64), values of val_bytes =
+ * 0 (keys only), 4 or 8.  Same DoubleBuffer/selector semantics as
+ * gs_lsb_sort_u32; bits [begin_bit, end_bit) with end_bit <= 8*key_bytes.
+ * General kernels (gs_wide.hip); the u32 / (u32,u32) cases are served faster
+ * by gs_lsb_sort_u32.                                                       */
+size_t gs_lsb_wide_temp_bytes(uint64_t num_items, int key_bytes, int val_bytes);
+int gs_lsb_sort_wide(void *d_temp, size_t temp_bytes, void *d_keys[2], void *d_vals[2],
+                     int *selector, uint64_t num_items, int key_bytes, int val_bytes,
+                     int begin_bit, int end_bit, int descending, int key_type, void *stream);
 
 /* Bring-up / test access to the three kernels of one pass (SURVEY.md 8a rows
  * L4-L6), all working on the same d_temp workspace (gs_lsb_temp_bytes):

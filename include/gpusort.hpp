@@ -10,8 +10,10 @@
 //   rdxsrt_unstable_sort_keys / _pairs            <- msb/src/sort/gpu_radix_sort.h:511,544
 //   RDXSRT_SortedSequence<K,V>                    <- msb/src/sort/gpu_radix_sort.h:31-34
 //
-// Supported key types: unsigned int, int, float (32-bit; the graded configurations are
-// u32); value type: any 4-byte trivially copyable type or NullType.
+// Supported key types: unsigned int, int, float (the graded configurations are u32) and,
+// through the DoubleBuffer overloads, unsigned long long, long long, double; value type:
+// any 4- or 8-byte trivially copyable type or NullType.  The plain-pointer (copy)
+// overloads and the MSB entry points are 32-bit only.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -40,6 +42,11 @@ template <typename K> struct KeyTraits;
 template <> struct KeyTraits<unsigned int> { static constexpr int type = GS_KEY_U32; };
 template <> struct KeyTraits<int> { static constexpr int type = GS_KEY_I32; };
 template <> struct KeyTraits<float> { static constexpr int type = GS_KEY_F32; };
+template <> struct KeyTraits<unsigned long long> { static constexpr int type = GS_KEY_U64; };
+template <> struct KeyTraits<unsigned long> { static constexpr int type = sizeof(unsigned long) == 8 ? GS_KEY_U64 : GS_KEY_U32; };
+template <> struct KeyTraits<long long> { static constexpr int type = GS_KEY_I64; };
+template <> struct KeyTraits<long> { static constexpr int type = sizeof(long) == 8 ? GS_KEY_I64 : GS_KEY_I32; };
+template <> struct KeyTraits<double> { static constexpr int type = GS_KEY_F64; };
 
 struct DeviceRadixSort {
     template <typename KeyT, typename ValueT>
@@ -47,7 +54,28 @@ struct DeviceRadixSort {
                                DoubleBuffer<ValueT> *d_values, int num_items, int begin_bit, int end_bit,
                                bool descending, hipStream_t stream)
     {
-        static_assert(sizeof(KeyT) == 4, "32-bit keys only");
+        constexpr int VB = std::is_same<ValueT, NullType>::value ? 0 : (int)sizeof(ValueT);
+        static_assert(sizeof(KeyT) == 4 || sizeof(KeyT) == 8, "32- or 64-bit keys");
+        static_assert(VB == 0 || VB == 4 || VB == 8, "32- or 64-bit values");
+        if constexpr (sizeof(KeyT) == 8 || VB == 8) {      // general kernels (gs_lsb_sort_wide)
+            const size_t need_w = gs_lsb_wide_temp_bytes((uint64_t)num_items, (int)sizeof(KeyT), d_values ? VB : 0);
+            if (d_temp_storage == nullptr) {
+                temp_storage_bytes = need_w;
+                return hipSuccess;
+            }
+            void *k2[2] = {d_keys.d_buffers[0], d_keys.d_buffers[1]};
+            void *v2[2] = {nullptr, nullptr};
+            if (d_values) { v2[0] = d_values->d_buffers[0]; v2[1] = d_values->d_buffers[1]; }
+            int sel_w = d_keys.selector;
+            const int err_w = gs_lsb_sort_wide(d_temp_storage, temp_storage_bytes, k2, d_values ? v2 : nullptr, &sel_w,
+                                               (uint64_t)num_items, (int)sizeof(KeyT), d_values ? VB : 0, begin_bit,
+                                               end_bit, descending ? 1 : 0, KeyTraits<KeyT>::type, stream);
+            if (err_w == 0) {
+                d_keys.selector = sel_w;
+                if (d_values) d_values->selector = sel_w;
+            }
+            return static_cast<hipError_t>(err_w);
+        }
         const size_t need = gs_lsb_temp_bytes((uint64_t)num_items, d_values != nullptr);
         if (d_temp_storage == nullptr) {            // size query (dispatch_radix_sort.cuh:1110)
             temp_storage_bytes = need;
@@ -57,7 +85,6 @@ struct DeviceRadixSort {
                              reinterpret_cast<uint32_t *>(d_keys.d_buffers[1])};
         uint32_t *vals[2] = {nullptr, nullptr};
         if (d_values) {
-            static_assert(std::is_same<ValueT, NullType>::value || sizeof(ValueT) == 4, "32-bit values only");
             vals[0] = reinterpret_cast<uint32_t *>(d_values->d_buffers[0]);
             vals[1] = reinterpret_cast<uint32_t *>(d_values->d_buffers[1]);
         }

@@ -231,6 +231,69 @@ void orc_lsb_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in,
     free(ranks);
 }
 
+/* ---- 64-bit keys: the same InitializeSolution logic for
+ * KeyT = unsigned long long / long long / double
+ * (test_device_radix_sort.cu:1244-1265 instantiates them).                    */
+/* util_type.cuh:966-974, 1009-1017, 1079-1089 with UnsignedBits = 64 bits */
+uint64_t orc_twiddle_in_u64(uint64_t k) { return k; }
+uint64_t orc_twiddle_in_i64(uint64_t k) { return k ^ 0x8000000000000000ull; }
+uint64_t orc_twiddle_in_f64(uint64_t k) { return k ^ ((k >> 63) ? ~0ull : 0x8000000000000000ull); }
+uint64_t orc_twiddle_out_f64(uint64_t k) { return k ^ ((k >> 63) ? 0x8000000000000000ull : ~0ull); }
+
+typedef struct { uint64_t key; uint32_t value; } orc_pair64_t;
+
+/* Pair::operator< : typed '<' for integers (test_device_radix_sort.cu:569-583),
+ * and for floating point '<' plus "-0 sorts before +0" (:588-612).  NaNs are
+ * never generated (test_util.h RandomBits rejects them).  key_type: 3 = u64,
+ * 4 = i64, 5 = f64 (gs_key_type in include/gpusort.h).                       */
+static int pair64_less(const orc_pair64_t *a, const orc_pair64_t *b, int key_type)
+{
+    if (key_type == 3) return a->key < b->key;
+    if (key_type == 4) return (int64_t)a->key < (int64_t)b->key;
+    double x, y;
+    memcpy(&x, &a->key, 8);
+    memcpy(&y, &b->key, 8);
+    if (x < y) return 1;
+    if (x > y) return 0;
+    return (a->key >> 63) != 0 && (b->key >> 63) == 0;
+}
+
+static void stable_sort_pairs64(orc_pair64_t *a, uint64_t n, int key_type)
+{
+    if (n < 2) return;
+    orc_pair64_t *tmp = (orc_pair64_t *)malloc(n * sizeof(orc_pair64_t));
+    orc_pair64_t *src = a, *dst = tmp;
+    for (uint64_t w = 1; w < n; w *= 2) {
+        for (uint64_t lo = 0; lo < n; lo += 2 * w) {
+            uint64_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            uint64_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) dst[k++] = pair64_less(&src[j], &src[i], key_type) ? src[j++] : src[i++];
+            while (i < mid) dst[k++] = src[i++];
+            while (j < hi) dst[k++] = src[j++];
+        }
+        orc_pair64_t *t = src; src = dst; dst = t;
+    }
+    if (src != a) memcpy(a, src, n * sizeof(orc_pair64_t));
+    free(tmp);
+}
+
+/* test_device_radix_sort.cu:634-693, KeyT 64 bits wide */
+void orc_lsb_reference_ranks_u64(const uint64_t *keys, uint64_t n, int key_type, int begin_bit,
+                                 int end_bit, int descending, uint32_t *ranks)
+{
+    orc_pair64_t *p = (orc_pair64_t *)malloc((n ? n : 1) * sizeof(orc_pair64_t));
+    int num_bits = end_bit - begin_bit;
+    for (uint64_t i = 0; i < n; ++i) {
+        p[i].key = (num_bits < 64) ? (keys[i] & (((1ull << num_bits) - 1) << begin_bit)) : keys[i];   /* :650-661 */
+        p[i].value = (uint32_t)i;
+    }
+    if (descending) for (uint64_t i = 0, j = n; i + 1 < j; ++i) { --j; orc_pair64_t t = p[i]; p[i] = p[j]; p[j] = t; }
+    stable_sort_pairs64(p, n, key_type);
+    if (descending) for (uint64_t i = 0, j = n; i + 1 < j; ++i) { --j; orc_pair64_t t = p[i]; p[i] = p[j]; p[j] = t; }
+    for (uint64_t i = 0; i < n; ++i) ranks[i] = p[i].value;
+    free(p);
+}
+
 /* ------------------------------------------------------ per-kernel goldens */
 
 void orc_chunk_tiles(uint64_t num_tiles, uint32_t tiles_per_chunk, uint32_t c,

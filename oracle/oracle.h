@@ -60,6 +60,13 @@ uint32_t orc_twiddle_out_f32(uint32_t k);
 /* ---- LSB oracle: InitializeSolution,
  *      lsb/cub/test/test_device_radix_sort.cu:634-693 (+ :888-889 values) -- */
 /* ranks[i] = original index of the i-th output element */
+/* 64-bit keys: key_type 3 = unsigned, 4 = signed, 5 = double (gs_key_type) */
+uint64_t orc_twiddle_in_u64(uint64_t k);
+uint64_t orc_twiddle_in_i64(uint64_t k);
+uint64_t orc_twiddle_in_f64(uint64_t k);
+uint64_t orc_twiddle_out_f64(uint64_t k);
+void orc_lsb_reference_ranks_u64(const uint64_t *keys, uint64_t n, int key_type, int begin_bit,
+                                 int end_bit, int descending, uint32_t *ranks);
 void orc_lsb_reference_ranks(const uint32_t *keys, uint64_t n, int begin_bit, int end_bit,
                              int descending, uint32_t *ranks);
 void orc_lsb_sort_keys(const uint32_t *keys_in, uint32_t *keys_out, uint64_t n,

@@ -50,6 +50,11 @@ def lib():
             getattr(L, name).restype = C.c_uint32
             getattr(L, name).argtypes = [C.c_uint32]
         L.orc_lsb_reference_ranks.argtypes = [_u32p, u64, i32, i32, i32, _u32p]
+        for name in ("orc_twiddle_in_u64", "orc_twiddle_in_i64", "orc_twiddle_in_f64", "orc_twiddle_out_f64"):
+            getattr(L, name).restype = u64
+            getattr(L, name).argtypes = [u64]
+        L.orc_lsb_reference_ranks_u64.argtypes = [np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS"), u64, i32, i32, i32,
+                                                  i32, _u32p]
         L.orc_lsb_sort_keys.argtypes = [_u32p, _u32p, u64, i32, i32, i32]
         L.orc_lsb_sort_pairs.argtypes = [_u32p, _u32p, _u32p, _u32p, u64, i32, i32, i32]
         L.orc_chunk_tiles.argtypes = [u64, C.c_uint32, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
@@ -133,6 +138,12 @@ def lsb_sort_pairs(keys, vals, begin_bit=0, end_bit=32, descending=False):
 def lsb_reference_ranks(keys, begin_bit=0, end_bit=32, descending=False):
     keys = _c(keys); r = np.empty(keys.size, np.uint32)
     lib().orc_lsb_reference_ranks(keys, keys.size, begin_bit, end_bit, int(descending), r); return r
+
+
+def lsb_reference_ranks_u64(keys, key_type=3, begin_bit=0, end_bit=64, descending=False):
+    """keys: uint64 bit patterns; key_type 3/4/5 = unsigned / signed / double."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64); r = np.empty(keys.size, np.uint32)
+    lib().orc_lsb_reference_ranks_u64(keys, keys.size, key_type, begin_bit, end_bit, int(descending), r); return r
 
 
 def chunk_tiles(num_tiles, tiles_per_chunk, c):

@@ -46,3 +46,10 @@ def test_msb_harness_entropy_sweep():
     out = _run(["msb_harness", "-r", "1", "-p", "80000", "--gtest_filter=Sort_Pairs.UINT_UINT"])
     text = "\n".join(out)
     assert "[       OK ] Sort_Pairs.UINT_UINT" in text and "FAILED" not in text
+
+
+def test_lsb_types_driver_all_type_pairs():
+    """Typed DeviceRadixSort driver (32- and 64-bit keys and values) against std::stable_sort."""
+    out = _run(["lsb_types", "200003"])
+    assert out[-1] == "ALL CORRECT" and not any("FAIL" in line for line in out)
+    assert sum(line.endswith(": CORRECT") for line in out) > 7 * 9

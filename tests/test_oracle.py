@@ -174,3 +174,31 @@ def test_cpu_baseline_sorts(oracle):
     dt, ks, vs = oracle.time_std_stable_sort_pairs(k & 0xFF, v)
     order = np.argsort(k & 0xFF, kind="stable")
     assert np.array_equal(vs, v[order])
+
+
+@pytest.mark.parametrize("kt,view", [(3, np.uint64), (4, np.int64), (5, np.float64)])
+def test_reference_ranks_64bit_match_numpy_stable_sort(oracle, kt, view):
+    rng = np.random.default_rng(kt)
+    k = rng.integers(0, 2**64, size=20011, dtype=np.uint64) & rng.integers(0, 2**64, size=20011, dtype=np.uint64)
+    if kt == 5:
+        k = k[~np.isnan(k.view(np.float64))]
+    assert np.array_equal(oracle.lsb_reference_ranks_u64(k, kt), np.argsort(k.view(view), kind="stable"))
+    r = oracle.lsb_reference_ranks_u64(k, kt, descending=True)           # reverse / stable sort / reverse
+    kk = k.view(view)[r]
+    assert np.all(kk[1:] <= kk[:-1])
+    ties = kk[1:] == kk[:-1]
+    assert np.all(r[1:][ties] > r[:-1][ties])                            # equal keys keep input order
+    m = oracle.lsb_reference_ranks_u64(k, 3, 31, 33)
+    assert np.array_equal(m, np.argsort((k >> np.uint64(31)) & np.uint64(3), kind="stable"))
+
+
+def test_twiddles_64bit_are_order_preserving(oracle):
+    L = oracle.lib()
+    f = np.array([-np.inf, -1e300, -2.5, -5e-324, -0.0, 0.0, 5e-324, 1.0, 1e300, np.inf])
+    t = [L.orc_twiddle_in_f64(int(x)) for x in f.view(np.uint64)]
+    assert t == sorted(t) and len(set(t)) == len(t)
+    assert [L.orc_twiddle_out_f64(x) for x in t] == [int(x) for x in f.view(np.uint64)]
+    i = np.array([-2**63, -5, -1, 0, 1, 2**63 - 1], dtype=np.int64)
+    t = [L.orc_twiddle_in_i64(int(x)) for x in i.view(np.uint64)]
+    assert t == sorted(t)
+    assert L.orc_twiddle_in_u64(12345) == 12345
