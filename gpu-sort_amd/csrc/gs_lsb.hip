@@ -193,32 +193,39 @@ __global__ __launch_bounds__(SCAN_THREADS) void lsb_scan_kernel(uint32_t *__rest
 // Two (pairs) or three (keys only) block barriers per tile.
 template <bool HAS_VALUES>
 struct DownsweepSmem {
-    uint32_t whist[LSB_WAVES][RADIX];                     // wave-private digit counters
+    uint32_t whist[LSB_WAVES][RADIX];                     // wave-private digit counters, then bases (byte offsets)
     uint16_t wbase[HAS_VALUES ? LSB_WAVES : 1][RADIX];    // pairs: tile-absolute base of (wave, digit), < 8192
     uint32_t gbase[RADIX];                                // global offset of digit run - tile-local start
-    union {                                               // the masks are dead once ranking is done
-        unsigned long long wmask[LSB_WAVES][RADIX];       // wave-private lane masks per digit (zero between rounds)
-        uint32_t stage[LSB_TILE * (HAS_VALUES ? 2 : 1)];  // tile in rank order; pairs interleaved {key,val}
-    };
+    uint32_t stage[LSB_TILE * (HAS_VALUES ? 2 : 1)];      // tile in rank order; pairs interleaved {key,val}
 };
 
-// Block i -> tile.  Blocks are dispatched in order, so the resident blocks work on
-// consecutive tiles; inside every group of
-// LSB_RESIDENT items the blocks of one XCD (same b % 8 under round-robin dispatch) take
-// a contiguous slice.  Speed only: any bijection gives the same result.
-__device__ __forceinline__ uint32_t tile_of_item(uint32_t i, uint32_t full_tiles)
-{
-    const uint32_t base = (i / LSB_RESIDENT) * LSB_RESIDENT;
-    if (base + LSB_RESIDENT > full_tiles) return i;   // ragged last group: identity
-    const uint32_t r = i - base;
-    return base + (r % MI355X_XCDS) * (LSB_RESIDENT / MI355X_XCDS) + r / MI355X_XCDS;
-}
+#ifdef GS_EXP_PHASES
+// experiment builds only (tools/phase_exp.py): shader-clock length of every phase of wave 0
+__device__ uint32_t gs_phase_buf[131072 * 16];   // [block][phase], n <= 2^30
+#define GS_PHASE(k)                                                                          \
+    do {                                                                                     \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                        \
+        if (tid == 0 && blockIdx.x < 131072u) gs_phase_buf[blockIdx.x * 16 + (k)] = (uint32_t)(now_ - tprev_); \
+        tprev_ = now_;                                                                       \
+    } while (0)
+#define GS_PHASE_WAIT(what) asm volatile("s_waitcnt " what ::: "memory")
+#else
+#define GS_PHASE(k) do { } while (0)
+#define GS_PHASE_WAIT(what) do { } while (0)
+#endif
 
+// The kernel is VALU-bound on MI355X (about 900 vector instructions per wave and tile, 57 % of
+// them the ballot match; measured with tools/phase_exp.py and an ISA count), so the template
+// parameters exist to keep instructions out of the hot variants:
 // TAIL = false: one of the array's FULL tiles.
 // TAIL = true: one block handles the last, partial tile (guarded loads); being
 // last in key order, its keys of digit d sit at the very end of digit d's global
 // range, so it needs only the digit totals.  Splitting it off keeps the guarded
 // path's registers out of the hot kernel.
+// TW: key transform on read / write.  0 = none (u32 ascending, and every middle pass: keys
+// travel twiddled between passes), 1 = xor mask (signed keys, descending), 2 = float + xor.
+// BIG = false: n <= 2^30, so byte offsets into the output fit 32 bits and a store needs no
+// 64-bit address arithmetic.
 // FUSED = true (single-sweep mode, see the host section): no upsweep/scan ran for this pass;
 // the tile learns its global offsets by decoupled look-back over `status`, one 32-bit word
 // per (tile, digit): bits 31:30 = 0 empty / 1 tile count / 2 inclusive prefix, bits 29:0 the
@@ -226,7 +233,7 @@ __device__ __forceinline__ uint32_t tile_of_item(uint32_t i, uint32_t full_tiles
 // and read by relaxed agent-scope loads (cdna_hip_programming.md Guideline 16, form R2).
 constexpr uint32_t ST_AGG = 1u << 30, ST_INC = 2u << 30, ST_VAL = (1u << 30) - 1u;
 
-template <bool HAS_VALUES, bool TAIL, bool FUSED = false, bool F32 = false>
+template <bool HAS_VALUES, bool TAIL, int TW, bool BIG, bool FUSED = false>
 __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep_kernel(
     const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint16_t *__restrict__ prefix16,
@@ -235,12 +242,60 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
 {
     __shared__ __attribute__((aligned(16))) DownsweepSmem<HAS_VALUES> sm;
     constexpr bool ALLWAVE = HAS_VALUES;   // see step 3
-    // F32 = false: the float twiddle is compiled out (u32 / i32 keys and every middle pass)
 
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const uint32_t full_tiles = p.n / (uint32_t)LSB_TILE;
+    auto tw_in = [&](uint32_t k) { return TW == 0 ? k : twiddle_in(k, TW == 2 ? p.f32_in : 0, p.xor_in); };
+    auto tw_out = [&](uint32_t k) { return TW == 0 ? k : twiddle_out(k, TW == 2 ? p.f32_out : 0, p.xor_out); };
+    // the digit width lives in a vector register: v_bfe_u32 takes one scalar operand (the shift)
+    uint32_t wbits = p.bits;
+    asm volatile("" : "+v"(wbits));
+    auto digit = [&](uint32_t k) { return __builtin_amdgcn_ubfe(k, p.shift, wbits); };
 
-    // wave 0, lane l: global start of digits 4l..4l+3 (exclusive scan of the totals)
+    uint32_t *my = sm.whist[w];
+    const uint16_t *mybase = sm.wbase[w];
+    const uint32_t wbase = (uint32_t)w * (WAVE * LSB_KPT) + lane;
+    const uint32_t tail_valid = p.n - full_tiles * (uint32_t)LSB_TILE;   // used when TAIL
+
+    if (!TAIL && blockIdx.x >= full_tiles) return;
+    const uint32_t t = TAIL ? full_tiles : tile_of_item(blockIdx.x, full_tiles);
+#ifdef GS_EXP_PHASES
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long t0_ = tprev_, r0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+    const uint64_t tile_base = (uint64_t)t * LSB_TILE;
+    const uint32_t valid = TAIL ? tail_valid : (uint32_t)LSB_TILE;
+
+    // 1. wave-striped coalesced load
+    uint32_t key[LSB_KPT], val[HAS_VALUES ? LSB_KPT : 1], pos[LSB_KPT];
+    {
+        const uint32_t *kin = keys_in + tile_base;
+        if (!TAIL) {
+#pragma unroll
+            for (int i = 0; i < LSB_KPT; ++i) key[i] = kin[wbase + i * WAVE];
+        } else {
+            // pad with keys whose twiddled form is all ones (largest digit; ranked after
+            // every real key of that digit because they sit at the tail)
+            const uint32_t pad = twiddle_out(0xffffffffu, TW == 2 ? p.f32_in : 0, TW ? p.xor_in : 0u);
+#pragma unroll
+            for (int i = 0; i < LSB_KPT; ++i) {
+                const uint32_t idx = wbase + i * WAVE;
+                key[i] = pad;
+                if (idx < tail_valid) key[i] = kin[idx];
+            }
+        }
+    }
+    GS_PHASE(0);                                   // load issue
+    if (HAS_VALUES) {
+        const uint32_t *vin = vals_in + tile_base;
+#pragma unroll
+        for (int i = 0; i < LSB_KPT; ++i) {
+            const uint32_t idx = wbase + i * WAVE;
+            val[i] = 0;
+            if (!TAIL || idx < valid) val[i] = vin[idx];
+        }
+    }
+    // (after the key loads are in flight) wave 0, lane l: global start of digits 4l..4l+3 (exclusive scan of the totals)
     // (TAIL: inclusive scan; the tile's own counts are subtracted later)
     uint32_t dstart[4] = {0, 0, 0, 0};
     if (w == 0) {
@@ -253,183 +308,155 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
         dstart[3] = dstart[2] + (TAIL ? tot.w : tot.z);
     }
 
-    uint32_t *my = sm.whist[w];
-    const uint16_t *mybase = sm.wbase[w];
-    unsigned long long *mm = sm.wmask[w];
-    const uint32_t half_bit = 1u << (lane & 31);
-    const uint32_t valu_rounds = p.valu_rounds;
-#pragma unroll
-    for (int i = lane; i < RADIX; i += WAVE) mm[i] = 0ull;   // invariant: all zero between rounds
-    const uint32_t wbase = (uint32_t)w * (WAVE * LSB_KPT) + lane;
-    const uint32_t tail_valid = p.n - full_tiles * (uint32_t)LSB_TILE;   // used when TAIL
-    uint32_t knext[LSB_KPT];   // raw keys of the tile
+    // this tile's global offsets (wave 0): scanned chunk count + count of the chunk's earlier tiles
+    uint32_t tbase[4] = {0, 0, 0, 0};
+    if (!TAIL && !FUSED && w == 0) {
+        const uint32_t *sp = spine + (uint32_t)(4 * lane) * p.grid + t / LSB_CHUNK;
+        const uint2 pf = reinterpret_cast<const uint2 *>(prefix16 + (size_t)t * RADIX)[lane];
+        tbase[0] = sp[0] + (pf.x & 0xffffu);
+        tbase[1] = sp[p.grid] + (pf.x >> 16);
+        tbase[2] = sp[2 * p.grid] + (pf.y & 0xffffu);
+        tbase[3] = sp[3 * p.grid] + (pf.y >> 16);
+    }
 
-    auto load_keys = [&](uint32_t t) {
-        const uint32_t *kin = keys_in + (uint64_t)t * LSB_TILE;
-        if (!TAIL) {
+    // global base of digit run = digit start + tile offset - tile-local start (wave 0, lane l: digits 4l..4l+3)
+    auto publish_gbase = [&](const uint32_t (&ex)[4], const uint32_t (&run)[4]) {
+        if (FUSED && !TAIL) {
+            // decoupled look-back (wave 0, lane l owns digits 4l..4l+3): publish this tile's
+            // counts, add up the predecessors' words walking backwards until an inclusive
+            // prefix is met, publish the own inclusive prefix.  Tiles are dispatched in order,
+            // so predecessors are resident or finished; every spin is bounded all the same.
+            uint32_t *mine = status + (size_t)t * RADIX + 4 * lane;
+            if (t == 0) {
 #pragma unroll
-            for (int i = 0; i < LSB_KPT; ++i) knext[i] = kin[wbase + i * WAVE];
-        } else {
-            // pad with keys whose twiddled form is all ones (largest digit; ranked after
-            // every real key of that digit because they sit at the tail)
-            const uint32_t pad = twiddle_out(0xffffffffu, (F32 ? p.f32_in : 0), p.xor_in);
+                for (int q = 0; q < 4; ++q) __hip_atomic_store(mine + q, ST_INC | run[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
 #pragma unroll
-            for (int i = 0; i < LSB_KPT; ++i) {
-                const uint32_t idx = wbase + i * WAVE;
-                knext[i] = pad;
-                if (idx < tail_valid) knext[i] = kin[idx];
+                for (int q = 0; q < 4; ++q) __hip_atomic_store(mine + q, ST_AGG | run[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t jq[4] = {t - 1, t - 1, t - 1, t - 1};
+                bool done[4] = {false, false, false, false};
+                uint32_t spins = 0;
+                for (;;) {
+                    uint32_t e[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        e[q] = done[q] ? 0u
+                                       : __hip_atomic_load(status + (size_t)jq[q] * RADIX + 4 * lane + q, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+                    bool waiting = false;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (done[q]) continue;
+                        const uint32_t f = e[q] >> 30;
+                        if (f == 0) { waiting = true; continue; }           // not published yet: retry
+                        tbase[q] += e[q] & ST_VAL;
+                        if (f == 2) done[q] = true; else --jq[q];             // tile 0 always publishes inclusive
+                    }
+                    const bool all_done = done[0] && done[1] && done[2] && done[3];
+                    if (__builtin_amdgcn_ballot_w64(!all_done) == 0) break;
+                    if (__builtin_amdgcn_ballot_w64(waiting) != 0) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1u << 22)) {                          // never hang the GPU
+                            if (lane == 0 && error_word) atomicOr(error_word, 1u);
+                            break;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    __hip_atomic_store(mine + q, ST_INC | ((tbase[q] + run[q]) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        uint32_t g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = dstart[q] + tbase[q] - ex[q];
+        if (TAIL) {   // keys of digit d end exactly at the inclusive total of d
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] -= run[q];
+            // padded keys inflate the count of the largest digit only, and they are never stored
+            const uint32_t pads = (uint32_t)LSB_TILE - valid, dmax = p.mask;
+            if (lane == (int)(dmax >> 2)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((dmax & 3u) == (uint32_t)q) g[q] += pads;
+            }
+        }
+        if (!BIG) {   // byte offsets (mod 2^32; exact once the slot is added)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] <<= 2;
+        }
+        reinterpret_cast<uint4 *>(sm.gbase)[lane] = make_uint4(g[0], g[1], g[2], g[3]);
     };
 
-    if (!TAIL && blockIdx.x >= full_tiles) return;
-    const uint32_t t = TAIL ? full_tiles : tile_of_item(blockIdx.x, full_tiles);
-    load_keys(t);
+    // 2. rank inside the wave (the LDS count of round i is consumed one round later, so
+    //    its latency hides behind the match of round i+1)
+#pragma unroll
+    for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
+    GS_PHASE_WAIT("vmcnt(0)");
+    GS_PHASE(1);                                   // load wait
+#pragma unroll
+    for (int i = 0; i < LSB_KPT; ++i) key[i] = tw_in(key[i]);
     {
-        const uint64_t tile_base = (uint64_t)t * LSB_TILE;
-        const uint32_t valid = TAIL ? tail_valid : (uint32_t)LSB_TILE;
-
-        uint32_t key[LSB_KPT], val[LSB_KPT], pos[LSB_KPT];
+        uint32_t d_prev = 0, plo = 0, phi = 0;
 #pragma unroll
-        for (int i = 0; i < LSB_KPT; ++i) key[i] = twiddle_in(knext[i], (F32 ? p.f32_in : 0), p.xor_in);
-        if (HAS_VALUES) {
-            const uint32_t *vin = vals_in + tile_base;
-#pragma unroll
-            for (int i = 0; i < LSB_KPT; ++i) {
-                const uint32_t idx = wbase + i * WAVE;
-                val[i] = 0;
-                if (!TAIL || idx < valid) val[i] = vin[idx];
+        for (int i = 0; i <= LSB_KPT; ++i) {
+            uint32_t d_cur = 0, clo = 0, chi = 0;
+            if (i < LSB_KPT) {
+                d_cur = digit(key[i]);
+                match_digit(d_cur, clo, chi);
             }
-        }
-        // this tile's global offsets (wave 0): scanned chunk count + count of the chunk's earlier tiles
-        uint32_t tbase[4] = {0, 0, 0, 0};
-        if (!TAIL && !FUSED && w == 0) {
-            const uint32_t *sp = spine + (uint32_t)(4 * lane) * p.grid + t / LSB_CHUNK;
-            const uint2 pf = reinterpret_cast<const uint2 *>(prefix16 + (size_t)t * RADIX)[lane];
-            tbase[0] = sp[0] + (pf.x & 0xffffu);
-            tbase[1] = sp[p.grid] + (pf.x >> 16);
-            tbase[2] = sp[2 * p.grid] + (pf.y & 0xffffu);
-            tbase[3] = sp[3 * p.grid] + (pf.y >> 16);
-        }
-
-        // global base of digit run = digit start + tile offset - tile-local start (wave 0, lane l: digits 4l..4l+3)
-        auto publish_gbase = [&](const uint32_t (&ex)[4], const uint32_t (&run)[4]) {
-            if (FUSED && !TAIL) {
-                // decoupled look-back (wave 0, lane l owns digits 4l..4l+3): publish this tile's
-                // counts, add up the predecessors' words walking backwards until an inclusive
-                // prefix is met, publish the own inclusive prefix.  Tiles are dispatched in order,
-                // so predecessors are resident or finished; every spin is bounded all the same.
-                uint32_t *mine = status + (size_t)t * RADIX + 4 * lane;
-                if (t == 0) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) __hip_atomic_store(mine + q, ST_INC | run[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) __hip_atomic_store(mine + q, ST_AGG | run[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    uint32_t jq[4] = {t - 1, t - 1, t - 1, t - 1};
-                    bool done[4] = {false, false, false, false};
-                    uint32_t spins = 0;
-                    for (;;) {
-                        uint32_t e[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            e[q] = done[q] ? 0u
-                                           : __hip_atomic_load(status + (size_t)jq[q] * RADIX + 4 * lane + q, __ATOMIC_RELAXED,
-                                                               __HIP_MEMORY_SCOPE_AGENT);
-                        bool waiting = false;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            if (done[q]) continue;
-                            const uint32_t f = e[q] >> 30;
-                            if (f == 0) { waiting = true; continue; }           // not published yet: retry
-                            tbase[q] += e[q] & ST_VAL;
-                            if (f == 2) done[q] = true; else --jq[q];             // tile 0 always publishes inclusive
-                        }
-                        const bool all_done = done[0] && done[1] && done[2] && done[3];
-                        if (__builtin_amdgcn_ballot_w64(!all_done) == 0) break;
-                        if (__builtin_amdgcn_ballot_w64(waiting) != 0) {
-                            __builtin_amdgcn_s_sleep(2);
-                            if (++spins > (1u << 22)) {                          // never hang the GPU
-                                if (lane == 0 && error_word) atomicOr(error_word, 1u);
-                                break;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        __hip_atomic_store(mine + q, ST_INC | ((tbase[q] + run[q]) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            if (i > 0) {
+                const uint32_t lower = count_lower(plo, phi);
+                pos[i - 1] = my[d_prev] + lower;            // LDS read, all lanes
+                if (lower == 0)                             // first lane of the group adds the group size
+                    __hip_atomic_fetch_add(&my[d_prev], (uint32_t)(__popc(plo) + __popc(phi)), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
-            uint32_t g[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) g[q] = dstart[q] + tbase[q] - ex[q];
-            if (TAIL) {   // keys of digit d end exactly at the inclusive total of d
-#pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] -= run[q];
-                // padded keys inflate the count of the largest digit only, and they are never stored
-                const uint32_t pads = (uint32_t)LSB_TILE - valid, dmax = p.mask;
-                if (lane == (int)(dmax >> 2)) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if ((dmax & 3u) == (uint32_t)q) g[q] += pads;
-                }
-            }
-            reinterpret_cast<uint4 *>(sm.gbase)[lane] = make_uint4(g[0], g[1], g[2], g[3]);
-        };
-
-        // 2. rank inside the wave (the LDS mask of round i is consumed one round later, so
-        //    its latency hides behind the issue of round i+1)
-#pragma unroll
-        for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
-        {
-            uint32_t d_prev = 0, plo = 0, phi = 0;
-#pragma unroll
-            for (int i = 0; i <= LSB_KPT; ++i) {
-                uint32_t d_cur = 0, clo = 0, chi = 0;
-                if (i < LSB_KPT) {
-                    d_cur = __builtin_amdgcn_ubfe(key[i], p.shift, p.bits);
-                    if ((valu_rounds >> i) & 1u) {
-                        match_digit(d_cur, clo, chi);
-                    } else {
-                        // each lane sets / reads / clears its own 32-bit half of the 64-bit entry
-                        uint32_t *half = reinterpret_cast<uint32_t *>(&mm[d_cur]) + (lane >> 5);
-                        __hip_atomic_fetch_or(half, half_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        const unsigned long long m =
-                            __hip_atomic_load(&mm[d_cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        __hip_atomic_store(half, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        clo = (uint32_t)m;
-                        chi = (uint32_t)(m >> 32);
-                    }
-                }
-                if (i > 0) {
-                    const uint32_t lower = count_lower(plo, phi);
-                    pos[i - 1] = my[d_prev] + lower;            // LDS read, all lanes
-                    if (lower == 0)                             // first lane of the group adds the group size
-                        __hip_atomic_fetch_add(&my[d_prev], (uint32_t)(__popc(plo) + __popc(phi)), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WAVEFRONT);
-                }
-                d_prev = d_cur; plo = clo; phi = chi;
-            }
+            d_prev = d_cur; plo = clo; phi = chi;
         }
+    }
 #pragma unroll
-        for (int i = 0; i < LSB_KPT; ++i) {
-            // finish the adds before the barrier, and make the keys opaque so their LDS
-            // histogram addresses are recomputed after the barrier instead of kept live
-            asm volatile("" : "+v"(pos[i]), "+v"(key[i]));
-        }
-        __syncthreads();
+    for (int i = 0; i < LSB_KPT; ++i) {
+        // finish the adds before the barrier, and make the keys opaque so their LDS
+        // histogram addresses are recomputed after the barrier instead of kept live
+        asm volatile("" : "+v"(pos[i]), "+v"(key[i]));
+    }
+    GS_PHASE_WAIT("lgkmcnt(0)");
+    GS_PHASE(2);                                   // rank
+    __syncthreads();
+    GS_PHASE(3);                                   // barrier 1
 
-        // 3. wave histograms -> tile-absolute base of every (wave, digit) + global base per digit.
-        //    4 digits per lane, b128 LDS accesses, DPP scan of the 256 digit totals.
-        if constexpr (ALLWAVE) {
-            // every wave sums the 8 rows and keeps only its own row's bases (own row of `wbase`), so
-            // there is no serial section and no second barrier: best at 2 blocks/CU (pairs)
-            uint32_t run[4] = {0, 0, 0, 0}, below[4] = {0, 0, 0, 0};
+    // 3. wave histograms -> tile-absolute base of every (wave, digit) + global base per digit.
+    //    4 digits per lane, b128 LDS accesses, DPP scan of the 256 digit totals.
+    if constexpr (ALLWAVE) {
+        // every wave sums the 8 rows and keeps only its own row's bases (own row of `wbase`), so
+        // there is no serial section and no second barrier: best at 2 blocks/CU (pairs)
+        uint32_t run[4] = {0, 0, 0, 0}, below[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < LSB_WAVES; ++j) {
+            const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
+            run[0] += x.x; run[1] += x.y; run[2] += x.z; run[3] += x.w;
+            if (j < w) { below[0] += x.x; below[1] += x.y; below[2] += x.z; below[3] += x.w; }
+        }
+        const uint32_t lane_sum = run[0] + run[1] + run[2] + run[3];
+        uint32_t ex[4];
+        ex[0] = wave_inclusive_scan(lane_sum) - lane_sum;
+        ex[1] = ex[0] + run[0];
+        ex[2] = ex[1] + run[1];
+        ex[3] = ex[2] + run[2];
+        reinterpret_cast<uint2 *>(sm.wbase[w])[lane] =
+            make_uint2((ex[0] + below[0]) | ((ex[1] + below[1]) << 16), (ex[2] + below[2]) | ((ex[3] + below[3]) << 16));
+        if (w == 0) publish_gbase(ex, run);
+    } else {
+        // wave 0 alone, two sweeps over the 8 rows (only one row in registers at a time), bases
+        // written back in place as BYTE offsets into `stage`; the other waves wait at the barrier
+        // while the CU's other two blocks run: best at 3 blocks/CU (keys only)
+        if (w == 0) {
+            uint32_t run[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < LSB_WAVES; ++j) {
                 const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
                 run[0] += x.x; run[1] += x.y; run[2] += x.z; run[3] += x.w;
-                if (j < w) { below[0] += x.x; below[1] += x.y; below[2] += x.z; below[3] += x.w; }
             }
             const uint32_t lane_sum = run[0] + run[1] + run[2] + run[3];
             uint32_t ex[4];
@@ -437,65 +464,75 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
             ex[1] = ex[0] + run[0];
             ex[2] = ex[1] + run[1];
             ex[3] = ex[2] + run[2];
-            reinterpret_cast<uint2 *>(sm.wbase[w])[lane] =
-                make_uint2((ex[0] + below[0]) | ((ex[1] + below[1]) << 16), (ex[2] + below[2]) | ((ex[3] + below[3]) << 16));
-            if (w == 0) publish_gbase(ex, run);
-        } else {
-            // wave 0 alone, two sweeps over the 8 rows (only one row in registers at a time), bases
-            // written back in place; the other waves wait at the barrier while the CU's other two
-            // blocks run: best at 3 blocks/CU (keys only)
-            if (w == 0) {
-                uint32_t run[4] = {0, 0, 0, 0};
+            publish_gbase(ex, run);
+            asm volatile("" ::: "memory");   // re-read the rows instead of keeping 32 registers live
+            uint4 e4 = make_uint4(ex[0] << 2, ex[1] << 2, ex[2] << 2, ex[3] << 2);
 #pragma unroll
-                for (int j = 0; j < LSB_WAVES; ++j) {
-                    const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
-                    run[0] += x.x; run[1] += x.y; run[2] += x.z; run[3] += x.w;
-                }
-                const uint32_t lane_sum = run[0] + run[1] + run[2] + run[3];
-                uint32_t ex[4];
-                ex[0] = wave_inclusive_scan(lane_sum) - lane_sum;
-                ex[1] = ex[0] + run[0];
-                ex[2] = ex[1] + run[1];
-                ex[3] = ex[2] + run[2];
-                publish_gbase(ex, run);
-                asm volatile("" ::: "memory");   // re-read the rows instead of keeping 32 registers live
-                uint4 e4 = make_uint4(ex[0], ex[1], ex[2], ex[3]);
-#pragma unroll
-                for (int j = 0; j < LSB_WAVES; ++j) {
-                    const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
-                    reinterpret_cast<uint4 *>(sm.whist[j])[lane] = e4;
-                    e4.x += x.x; e4.y += x.y; e4.z += x.z; e4.w += x.w;
-                }
+            for (int j = 0; j < LSB_WAVES; ++j) {
+                const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
+                reinterpret_cast<uint4 *>(sm.whist[j])[lane] = e4;
+                e4.x += x.x << 2; e4.y += x.y << 2; e4.z += x.z << 2; e4.w += x.w << 2;
             }
-            __syncthreads();
-        }
-
-        // 4. tile -> LDS in rank order -> global
-#pragma unroll
-        for (int i = 0; i < LSB_KPT; ++i) {
-            const uint32_t d = __builtin_amdgcn_ubfe(key[i], p.shift, p.bits);
-            const uint32_t at = pos[i] + (ALLWAVE ? (uint32_t)mybase[d] : my[d]);
-            if (HAS_VALUES) reinterpret_cast<uint2 *>(sm.stage)[at] = make_uint2(key[i], val[i]);
-            else sm.stage[at] = key[i];
         }
         __syncthreads();
+    }
+    GS_PHASE(4);                                   // scan + barrier 2
+
+    // 4. tile -> LDS in rank order -> global.  All 16 base reads are issued before the first
+    //    write so the LDS round trip is paid once, not per key.
+    {
+        uint32_t wb[LSB_KPT];
 #pragma unroll
         for (int i = 0; i < LSB_KPT; ++i) {
-            const uint32_t slot = (uint32_t)tid + i * LSB_THREADS;
-            uint32_t k, v = 0;
+            const uint32_t d = digit(key[i]);
+            wb[i] = ALLWAVE ? (uint32_t)mybase[d] : my[d];
+        }
+#pragma unroll
+        for (int i = 0; i < LSB_KPT; ++i) {
             if (HAS_VALUES) {
-                const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[slot];
-                k = kv.x; v = kv.y;
+                reinterpret_cast<uint2 *>(sm.stage)[pos[i] + wb[i]] = make_uint2(key[i], val[i]);
             } else {
-                k = sm.stage[slot];
-            }
-            const uint32_t dst = sm.gbase[__builtin_amdgcn_ubfe(k, p.shift, p.bits)] + slot;
-            if (!TAIL || slot < valid) {
-                keys_out[dst] = twiddle_out(k, (F32 ? p.f32_out : 0), p.xor_out);
-                if (HAS_VALUES) vals_out[dst] = v;
+                const uint32_t at = (pos[i] << 2) + wb[i];       // bytes
+                *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(sm.stage) + at) = key[i];
             }
         }
     }
+    GS_PHASE_WAIT("lgkmcnt(0)");
+    GS_PHASE(5);                                   // LDS scatter
+    __syncthreads();
+    GS_PHASE(6);                                   // barrier 3
+#pragma unroll
+    for (int i = 0; i < LSB_KPT; ++i) {
+        const uint32_t slot = (uint32_t)tid + i * LSB_THREADS;
+        uint32_t k, v = 0;
+        if (HAS_VALUES) {
+            const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[slot];
+            k = kv.x; v = kv.y;
+        } else {
+            k = sm.stage[slot];
+        }
+        const uint32_t g = sm.gbase[digit(k)];
+        if (!TAIL || slot < valid) {
+            if (BIG) {
+                const uint32_t dst = g + slot;
+                keys_out[dst] = tw_out(k);
+                if (HAS_VALUES) vals_out[dst] = v;
+            } else {
+                const uint32_t off = g + slot * 4u;             // 32-bit byte offset: scalar base + vector offset
+                *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(keys_out) + off) = tw_out(k);
+                if (HAS_VALUES) *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(vals_out) + off) = v;
+            }
+        }
+    }
+    GS_PHASE(7);                                   // store issue
+    GS_PHASE_WAIT("vmcnt(0)");
+    GS_PHASE(8);                                   // store drain
+#ifdef GS_EXP_PHASES
+    if (tid == 0 && blockIdx.x < 131072u) {        // clock calibration: shader clocks vs 100 MHz real time
+        gs_phase_buf[blockIdx.x * 16 + 9] = (uint32_t)(__builtin_amdgcn_s_memtime() - t0_);
+        gs_phase_buf[blockIdx.x * 16 + 10] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - r0_);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------- host --
@@ -535,8 +572,6 @@ PassParams lsb_make_params(uint64_t n, int shift, int bits)
     p.shift = (uint32_t)shift;
     p.bits = (uint32_t)bits;
     p.mask = (1u << bits) - 1u;
-    static const char *e = getenv("GS_VALU_ROUNDS");   // experiments only
-    p.valu_rounds = e ? (uint32_t)strtoul(e, nullptr, 0) : 0xffffu;   // measured best at 3 blocks/CU
     return p;
 }
 
@@ -586,35 +621,46 @@ int lsb_scan(uint32_t *spine, uint32_t *totals, uint32_t grid, hipStream_t s)
     return (int)hipGetLastError();
 }
 
-template <bool F32>
+template <int TW, bool BIG>
 static void launch_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, const uint32_t *spine,
                              const uint16_t *prefix16, const uint32_t *totals, const PassParams &p, hipStream_t s)
 {
     const dim3 block(LSB_THREADS);
-    if (p.n >= (uint32_t)LSB_TILE) {   // full tiles
-        if (vin)
-            hipLaunchKernelGGL((lsb_downsweep_kernel<true, false, false, F32>), dim3(p.ds_grid), block, 0, s, kin, kout, vin,
-                               vout, spine, prefix16, totals, p, (uint32_t *)nullptr, (uint32_t *)nullptr);
-        else
-            hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, false, F32>), dim3(p.ds_grid), block, 0, s, kin, kout,
-                               vin, vout, spine, prefix16, totals, p, (uint32_t *)nullptr, (uint32_t *)nullptr);
-    }
-    if (p.n % (uint32_t)LSB_TILE) {    // the partial last tile, if any
-        if (vin)
-            hipLaunchKernelGGL((lsb_downsweep_kernel<true, true, false, F32>), dim3(1), block, 0, s, kin, kout, vin, vout,
-                               spine, prefix16, totals, p, (uint32_t *)nullptr, (uint32_t *)nullptr);
-        else
-            hipLaunchKernelGGL((lsb_downsweep_kernel<false, true, false, F32>), dim3(1), block, 0, s, kin, kout, vin, vout,
-                               spine, prefix16, totals, p, (uint32_t *)nullptr, (uint32_t *)nullptr);
-    }
+    if (vin)
+        hipLaunchKernelGGL((lsb_downsweep_kernel<true, false, TW, BIG>), dim3(p.ds_grid), block, 0, s, kin, kout, vin, vout,
+                           spine, prefix16, totals, p, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    else
+        hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, TW, BIG>), dim3(p.ds_grid), block, 0, s, kin, kout, vin, vout,
+                           spine, prefix16, totals, p, (uint32_t *)nullptr, (uint32_t *)nullptr);
+}
+
+static void launch_downsweep_tail(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                                  const uint32_t *totals, const PassParams &p, hipStream_t s)
+{
+    const dim3 block(LSB_THREADS);   // one block, the general variant
+    if (vin)
+        hipLaunchKernelGGL((lsb_downsweep_kernel<true, true, 2, true>), dim3(1), block, 0, s, kin, kout, vin, vout,
+                           (const uint32_t *)nullptr, (const uint16_t *)nullptr, totals, p, (uint32_t *)nullptr,
+                           (uint32_t *)nullptr);
+    else
+        hipLaunchKernelGGL((lsb_downsweep_kernel<false, true, 2, true>), dim3(1), block, 0, s, kin, kout, vin, vout,
+                           (const uint32_t *)nullptr, (const uint16_t *)nullptr, totals, p, (uint32_t *)nullptr,
+                           (uint32_t *)nullptr);
 }
 
 int lsb_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, const uint32_t *spine,
                   const uint16_t *prefix16, const uint32_t *totals, const PassParams &p, hipStream_t s)
 {
     KernelTimer kt(GS_K_LSB_DOWNSWEEP, s);
-    if (p.f32_in || p.f32_out) launch_downsweep<true>(kin, kout, vin, vout, spine, prefix16, totals, p, s);
-    else launch_downsweep<false>(kin, kout, vin, vout, spine, prefix16, totals, p, s);
+    if (p.n >= (uint32_t)LSB_TILE) {   // full tiles
+        const int tw = (p.f32_in || p.f32_out) ? 2 : ((p.xor_in | p.xor_out) ? 1 : 0);
+        const bool big = p.n > (1u << 30);
+#define GS_DS(TW_, BIG_) launch_downsweep<TW_, BIG_>(kin, kout, vin, vout, spine, prefix16, totals, p, s)
+        if (big) { if (tw == 2) GS_DS(2, true); else if (tw == 1) GS_DS(1, true); else GS_DS(0, true); }
+        else { if (tw == 2) GS_DS(2, false); else if (tw == 1) GS_DS(1, false); else GS_DS(0, false); }
+#undef GS_DS
+    }
+    if (p.n % (uint32_t)LSB_TILE) launch_downsweep_tail(kin, kout, vin, vout, totals, p, s);   // the partial last tile
     return (int)hipGetLastError();
 }
 
@@ -671,21 +717,14 @@ static int lsb_run_passes(const LsbWorkspace &ws, uint64_t num_items, int begin_
             KernelTimer kt(GS_K_LSB_DOWNSWEEP, s);
             const dim3 block(LSB_THREADS);
             if (vin)
-                hipLaunchKernelGGL((lsb_downsweep_kernel<true, false, true, true>), dim3(p.ds_grid), block, 0, s, kin, kout, vin,
-                                   vout, (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, ws.status, ws.error_word);
+                hipLaunchKernelGGL((lsb_downsweep_kernel<true, false, 2, false, true>), dim3(p.ds_grid), block, 0, s, kin, kout,
+                                   vin, vout, (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, ws.status,
+                                   ws.error_word);
             else
-                hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, true, true>), dim3(p.ds_grid), block, 0, s, kin, kout, vin,
-                                   vout, (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, ws.status, ws.error_word);
-            if (p.n % (uint32_t)LSB_TILE) {
-                if (vin)
-                    hipLaunchKernelGGL((lsb_downsweep_kernel<true, true, false, true>), dim3(1), block, 0, s, kin, kout, vin, vout,
-                                       (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, (uint32_t *)nullptr,
-                                       (uint32_t *)nullptr);
-                else
-                    hipLaunchKernelGGL((lsb_downsweep_kernel<false, true, false, true>), dim3(1), block, 0, s, kin, kout, vin, vout,
-                                       (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, (uint32_t *)nullptr,
-                                       (uint32_t *)nullptr);
-            }
+                hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, 2, false, true>), dim3(p.ds_grid), block, 0, s, kin, kout,
+                                   vin, vout, (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, ws.status,
+                                   ws.error_word);
+            if (p.n % (uint32_t)LSB_TILE) launch_downsweep_tail(kin, kout, vin, vout, tot, p, s);
         }
         if ((e = (int)hipGetLastError())) return e;
     }
@@ -697,6 +736,13 @@ static int lsb_run_passes(const LsbWorkspace &ws, uint64_t num_items, int begin_
 using namespace gs;
 
 extern "C" {
+
+#ifdef GS_EXP_PHASES
+int gs_exp_phases(uint32_t *host_out, uint32_t blocks)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(gs_phase_buf), (size_t)blocks * 16 * sizeof(uint32_t));
+}
+#endif
 
 size_t gs_lsb_temp_bytes(uint64_t num_items, int /*has_values*/)
 {

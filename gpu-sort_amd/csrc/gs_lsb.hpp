@@ -27,8 +27,19 @@ struct PassParams {
     uint32_t mask;
     int f32_in, f32_out;          // float twiddle on read / undo on write
     uint32_t xor_in, xor_out;     // uniform xor on read / write (sign flip, descending)
-    uint32_t valu_rounds;         // bit i set: round i matches with VALU ballots, else through LDS
 };
+
+// Block i -> tile.  Blocks are dispatched in order, so the resident blocks work on
+// consecutive tiles; inside every group of
+// LSB_RESIDENT items the blocks of one XCD (same b % 8 under round-robin dispatch) take
+// a contiguous slice.  Speed only: any bijection gives the same result.
+__device__ __forceinline__ uint32_t tile_of_item(uint32_t i, uint32_t full_tiles)
+{
+    const uint32_t base = (i / LSB_RESIDENT) * LSB_RESIDENT;
+    if (base + LSB_RESIDENT > full_tiles) return i;   // ragged last group: identity
+    const uint32_t r = i - base;
+    return base + (r % MI355X_XCDS) * (LSB_RESIDENT / MI355X_XCDS) + r / MI355X_XCDS;
+}
 
 struct LsbWorkspace {
     uint32_t *spine;

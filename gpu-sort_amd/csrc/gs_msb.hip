@@ -29,6 +29,8 @@
 //     LSB path; the scatter of an unstable partition ranks with LDS atomics.
 #include "gs_device.hpp"
 #include "gs_lsb.hpp"
+#include <type_traits>
+#include <cstdlib>
 
 namespace gs {
 
@@ -46,6 +48,7 @@ __host__ __device__ constexpr uint32_t msb_class_cap(int c) { return (uint32_t)m
 __host__ __device__ constexpr int msb_num_classes(bool has_values) { return has_values ? 3 : 4; }
 
 struct MsbBucket { uint32_t offset, size, tile_start, pad; };   // a bucket still to be partitioned
+struct MsbTile { uint32_t lo, valid, bucket, pad; };            // one tile of a level: keys [lo, lo + valid)
 struct MsbTask { uint32_t offset, size, sort_bits, pad; };      // a range to finish with a local sort
 struct MsbLevel {
     unsigned long long packed;           // hi32: buckets to partition at this level, lo32: their tiles
@@ -53,12 +56,21 @@ struct MsbLevel {
     uint32_t pad[2];
 };
 
+// A level is partitioned like an LSB pass over its tiles (no atomics, deterministic): the tiles of
+// all its buckets are numbered consecutively, 8 consecutive tiles form a chunk,
+//   spine[d][c]       keys of digit d in chunk c, scanned in place over the whole level,
+//   prefix16[g][d]    keys of digit d in the tiles of g's chunk before g,
+// so E(g, d) = spine[d][g / 8] + prefix16[g][d] counts digit d in ALL level tiles before g, and a
+// bucket's tile g finds its offset inside sub-bucket d as E(g, d) - E(first tile of the bucket, d).
 struct MsbWs {
     MsbLevel *level;                     // [5]
     MsbBucket *buckets[2];               // level L uses buckets[L & 1]
-    uint32_t *hist[2];                   // [max_buckets][256]: counts, then scatter cursors
+    MsbTile *tiles;                      // tile records of the current level
+    uint32_t *cursors;                   // [max_buckets][256]: sub-bucket start - E(first tile, d)
+    uint32_t *spine;                     // [256][stride]
+    uint16_t *prefix16;                  // [max_tiles][256]
     MsbTask *tasks[MSB_NCLASS];
-    uint32_t max_buckets, max_tasks;
+    uint32_t max_buckets, max_tasks, max_tiles, stride;
 };
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -72,21 +84,33 @@ static inline uint32_t msb_max_tasks(uint64_t n, bool has_values)
     // plus up to 256 per partitioned bucket
     return (uint32_t)(2 * n / MSB_MERGE) + msb_max_buckets(n, has_values) + 2 * RADIX;
 }
+// tiles of a level: n / TILE full ones + one ragged tile per bucket, padded to whole chunks + one spare chunk
+static inline uint32_t msb_max_tiles(uint64_t n, bool has_values)
+{
+    const uint64_t t = n / MSB_TILE + msb_max_buckets(n, has_values) + 1;
+    return (uint32_t)((t / MSB_WAVES + 2) * MSB_WAVES);
+}
 static size_t msb_ws_bytes(uint64_t n, bool has_values)
 {
-    const size_t mb = msb_max_buckets(n, has_values), mt = msb_max_tasks(n, has_values);
-    return align256(5 * sizeof(MsbLevel)) + 2 * align256(mb * sizeof(MsbBucket)) + 2 * align256(mb * RADIX * sizeof(uint32_t)) +
-           MSB_NCLASS * align256(mt * sizeof(MsbTask));
+    const size_t mb = msb_max_buckets(n, has_values), mt = msb_max_tasks(n, has_values), ml = msb_max_tiles(n, has_values);
+    return align256(5 * sizeof(MsbLevel)) + 2 * align256(mb * sizeof(MsbBucket)) + align256(ml * sizeof(MsbTile)) +
+           align256(mb * RADIX * sizeof(uint32_t)) + align256((size_t)RADIX * (ml / MSB_WAVES) * sizeof(uint32_t)) +
+           align256(ml * RADIX * sizeof(uint16_t)) + MSB_NCLASS * align256(mt * sizeof(MsbTask));
 }
 static MsbWs msb_carve(void *temp, uint64_t n, bool has_values)
 {
     MsbWs ws;
     ws.max_buckets = msb_max_buckets(n, has_values);
     ws.max_tasks = msb_max_tasks(n, has_values);
+    ws.max_tiles = msb_max_tiles(n, has_values);
+    ws.stride = ws.max_tiles / MSB_WAVES;
     char *c = (char *)temp;
     ws.level = (MsbLevel *)c; c += align256(5 * sizeof(MsbLevel));
     for (int i = 0; i < 2; ++i) { ws.buckets[i] = (MsbBucket *)c; c += align256((size_t)ws.max_buckets * sizeof(MsbBucket)); }
-    for (int i = 0; i < 2; ++i) { ws.hist[i] = (uint32_t *)c; c += align256((size_t)ws.max_buckets * RADIX * sizeof(uint32_t)); }
+    ws.tiles = (MsbTile *)c; c += align256((size_t)ws.max_tiles * sizeof(MsbTile));
+    ws.cursors = (uint32_t *)c; c += align256((size_t)ws.max_buckets * RADIX * sizeof(uint32_t));
+    ws.spine = (uint32_t *)c; c += align256((size_t)RADIX * ws.stride * sizeof(uint32_t));
+    ws.prefix16 = (uint16_t *)c; c += align256((size_t)ws.max_tiles * RADIX * sizeof(uint16_t));
     for (int i = 0; i < MSB_NCLASS; ++i) { ws.tasks[i] = (MsbTask *)c; c += align256((size_t)ws.max_tasks * sizeof(MsbTask)); }
     return ws;
 }
@@ -112,20 +136,21 @@ __global__ void msb_single_task_kernel(MsbWs ws, uint32_t n, int cls)
     }
 }
 
-// bucket that owns global tile index g (buckets are appended with increasing tile_start)
-__device__ __forceinline__ uint32_t msb_find_bucket(const MsbBucket *__restrict__ b, uint32_t count, uint32_t g)
+// tile records of level L from its bucket list (one block per bucket and step)
+__global__ __launch_bounds__(256) void msb_expand_kernel(MsbWs ws, int L)
 {
-    uint32_t lo = 0, hi = count;          // last entry with tile_start <= g
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (b[mid].tile_start <= g) lo = mid; else hi = mid;
+    const uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const MsbBucket B = ws.buckets[L & 1][b];
+        const uint32_t tiles = (B.size + MSB_TILE - 1) / MSB_TILE;
+        for (uint32_t t = threadIdx.x; t < tiles; t += blockDim.x) {
+            const uint32_t lo = B.offset + t * MSB_TILE, left = B.size - t * MSB_TILE;
+            ws.tiles[B.tile_start + t] = MsbTile{lo, left < (uint32_t)MSB_TILE ? left : (uint32_t)MSB_TILE, b, 0u};
+        }
     }
-    return lo;
 }
 
-// -------------------------------------------------------------- histogram --
-// M3: 256-bin histogram of byte `shift/8` for every tile of every bucket of level L,
-// accumulated per bucket with one global atomic per non-empty bin and tile.
+// ---------------------------------------------------------------- upsweep --
 // digit of a key: byte `shift/8`, or -- multi-GPU sharding -- the destination rank looked up
 // from the key's top bits: remap[twiddle_in(key) >> rshift]
 struct DigitSel {
@@ -138,11 +163,6 @@ struct DigitSel {
 constexpr int SHARD_MAX_BITS = 12;   // 4096 bins of the key space
 // `tab`: the remap table staged in LDS by load_remap (global gathers of a 4 KiB table cost more
 // than the rest of the kernel)
-__device__ __forceinline__ uint32_t digit_of(const DigitSel &ds, const uint8_t *tab, uint32_t k)
-{
-    if (ds.remap) return tab[twiddle_in(k, ds.f32_in, ds.xor_in) >> ds.rshift];
-    return (k >> ds.shift) & 255u;
-}
 __device__ __forceinline__ void load_remap(const DigitSel &ds, uint8_t *tab)
 {
     if (ds.remap) {
@@ -152,59 +172,96 @@ __device__ __forceinline__ void load_remap(const DigitSel &ds, uint8_t *tab)
     }
 }
 
-__global__ __launch_bounds__(MSB_THREADS) void msb_hist_kernel(MsbWs ws, int L, const uint32_t *__restrict__ src, DigitSel ds)
+template <bool REMAP>
+__device__ __forceinline__ uint32_t msb_digit(const DigitSel &ds, const uint8_t *tab, uint32_t k)
+{
+    if (REMAP) return tab[twiddle_in(k, ds.f32_in, ds.xor_in) >> ds.rshift];
+    return __builtin_amdgcn_ubfe(k, (uint32_t)ds.shift, 8u);
+}
+
+// M3 as an upsweep: one block per chunk of 8 level tiles, one WAVE per tile (wave-private LDS
+// counters, 32 dword loads in flight per lane: bucket offsets are not 16-byte aligned).
+template <bool REMAP>
+__global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int L, const uint32_t *__restrict__ src, DigitSel ds)
 {
     __shared__ uint32_t lh[MSB_WAVES][RADIX];
-    __shared__ uint8_t tab[1 << SHARD_MAX_BITS];
-    load_remap(ds, tab);
-    const unsigned long long packed = ws.level[L].packed;
-    const uint32_t nb = (uint32_t)(packed >> 32), ntiles = (uint32_t)packed;
+    __shared__ uint8_t tab[REMAP ? (1 << SHARD_MAX_BITS) : 4];
+    if (REMAP) load_remap(ds, tab);
+    const uint32_t ntiles = (uint32_t)ws.level[L].packed;
+    const uint32_t nchunks = ntiles / MSB_WAVES + 1;          // covers tile index `ntiles` too (see classify)
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    const MsbBucket *bk = ws.buckets[L & 1];
     uint32_t *my = lh[w];
-    for (uint32_t g = blockIdx.x; g < ntiles; g += gridDim.x) {
-        const uint32_t b = msb_find_bucket(bk, nb, g);
-        const MsbBucket B = bk[b];
-        const uint32_t lo = B.offset + (g - B.tile_start) * MSB_TILE;
-        const uint32_t end = B.offset + B.size;
-        const uint32_t len = (end - lo < (uint32_t)MSB_TILE) ? end - lo : (uint32_t)MSB_TILE;
+    constexpr int BATCH = 32;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
 #pragma unroll
         for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
-        const uint32_t *p = src + lo;
-        // 16-byte loads over the aligned middle of the tile, scalar head and tail
-        uint32_t head = (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) >> 2;
-        if (head > len) head = len;
-        const uint32_t nvec = (len - head) >> 2;
-        const uint4 *p4 = reinterpret_cast<const uint4 *>(p + head);
-        for (uint32_t v = (uint32_t)tid; v < nvec; v += MSB_THREADS) {
-            const uint4 q = p4[v];
-            hist_add(my, digit_of(ds, tab, q.x)); hist_add(my, digit_of(ds, tab, q.y));
-            hist_add(my, digit_of(ds, tab, q.z)); hist_add(my, digit_of(ds, tab, q.w));
+        const uint32_t g = c * MSB_WAVES + (uint32_t)w;
+        if (g < ntiles) {
+            const MsbTile T = ws.tiles[g];
+            const uint32_t *p = src + T.lo;
+            auto count = [&](uint32_t k) { hist_add(my, msb_digit<REMAP>(ds, tab, k)); };
+            if (T.valid == (uint32_t)MSB_TILE) {
+#pragma unroll
+                for (int j = 0; j < MSB_TILE / WAVE; j += BATCH) {
+                    uint32_t v[BATCH];
+#pragma unroll
+                    for (int u = 0; u < BATCH; ++u) v[u] = p[(j + u) * WAVE + lane];
+#pragma unroll
+                    for (int u = 0; u < BATCH; ++u) count(v[u]);
+                }
+            } else {
+                for (uint32_t i = lane; i < T.valid; i += WAVE) count(p[i]);
+            }
         }
-        if ((uint32_t)tid < head) hist_add(my, digit_of(ds, tab, p[tid]));
-        const uint32_t tail0 = head + (nvec << 2);
-        if (tail0 + (uint32_t)tid < len) hist_add(my, digit_of(ds, tab, p[tail0 + tid]));
         __syncthreads();
         if (tid < RADIX) {
-            uint32_t s = 0;
+            uint32_t run = 0;
 #pragma unroll
-            for (int j = 0; j < MSB_WAVES; ++j) s += lh[j][tid];
-            if (s) atomicAdd(&ws.hist[L & 1][(size_t)b * RADIX + tid], s);
+            for (int j = 0; j < MSB_WAVES; ++j) {
+                ws.prefix16[(size_t)(c * MSB_WAVES + j) * RADIX + tid] = (uint16_t)run;
+                run += lh[j][tid];
+            }
+            ws.spine[(size_t)tid * ws.stride + c] = run;
         }
         __syncthreads();
     }
 }
 
+// exclusive scan of every spine row over the level's chunks (one block per digit)
+__global__ __launch_bounds__(1024) void msb_scan_kernel(MsbWs ws, int L)
+{
+    __shared__ uint32_t wsum[16];
+    const uint32_t nchunks = (uint32_t)ws.level[L].packed / MSB_WAVES + 1;
+    uint32_t *row = ws.spine + (size_t)blockIdx.x * ws.stride;
+    const int w = wave_id(), lane = lane_id();
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nchunks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t c = (i < nchunks) ? row[i] : 0u;
+        const uint32_t inc = wave_inclusive_scan(c);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        const uint32_t s = (lane < 16) ? wsum[lane] : 0u;
+        const uint32_t wincl = wave_inclusive_scan(s);
+        const uint32_t wbase_ = __shfl(wincl - s, w, WAVE);
+        const uint32_t seg_total = __shfl(wincl, 15, WAVE);
+        if (i < nchunks) row[i] = carry + wbase_ + inc - c;
+        carry += seg_total;
+        __syncthreads();
+    }
+}
+
 // --------------------------------------------------------------- classify --
-// M4: per bucket of level L turn the 256 counts into absolute sub-bucket offsets
-// (the scatter's cursors) and decide what happens to every sub-bucket next:
+// M4: per bucket of level L turn the 256 sub-bucket counts into absolute offsets (the downsweep's
+// cursors) and decide what happens to every sub-bucket next:
 //   empty                      -> nothing
 //   > largest local capacity   -> bucket of level L+1 (partitioned on the next byte)
 //   otherwise                  -> local-sort task; adjacent sub-buckets are merged
 //                                 greedily while the running sum is < MSB_MERGE and
 //                                 still fits (a merged task also re-sorts this byte).
+// The counts are differences of the scanned upsweep: E(g, d) over the bucket's tile range.
 // LAST (byte 0): only the cursors are needed, the scatter finishes everything.
-// `counts0`: level 0 of the sort reads the LSB pass's digit totals instead of a histogram row
+// `counts0`: level 0 of the sort reads the LSB pass's digit totals instead
 // (and needs no cursors: the LSB downsweep does that scatter).
 template <bool LAST>
 __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, const uint32_t *__restrict__ counts0, int nclass)
@@ -220,11 +277,18 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
     const uint32_t rb = 24u - 8u * (uint32_t)L;                  // bits below this level's byte
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const MsbBucket B = ws.buckets[L & 1][b];
-        uint32_t *row = ws.hist[L & 1] + (size_t)b * RADIX;
-        const uint32_t c = counts0 ? counts0[d] : row[d];
+        uint32_t c, e0 = 0;
+        if (counts0) {
+            c = counts0[d];
+        } else {
+            const uint32_t g0 = B.tile_start, g1 = g0 + (B.size + MSB_TILE - 1) / MSB_TILE;
+            const uint32_t *srow = ws.spine + (size_t)d * ws.stride;
+            e0 = srow[g0 / MSB_WAVES] + ws.prefix16[(size_t)g0 * RADIX + d];
+            c = srow[g1 / MSB_WAVES] + ws.prefix16[(size_t)g1 * RADIX + d] - e0;
+        }
         const uint32_t ex = block_exclusive_scan_256(c, scratch, nullptr);
         const uint32_t abs = B.offset + ex;
-        if (!counts0) row[d] = abs;
+        if (!counts0) ws.cursors[(size_t)b * RADIX + d] = abs - e0;
         if (LAST) continue;
         s_cnt[d] = c; s_abs[d] = abs; s_task[d] = 0; s_nsub[d] = 0; s_large[d] = 0;
         if (d < MSB_NCLASS) s_ccnt[d] = 0;
@@ -280,113 +344,233 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
         } else if (tsize) {
             ws.tasks[cls][s_cbase[cls] + task_local] = MsbTask{abs, tsize, rb + (s_nsub[d] > 1 ? 8u : 0u), 0u};
         }
-        // clear the histogram rows of the buckets just created (all threads help)
-        s_cnt[d] = new_bucket;
-        __syncthreads();
-        for (int q = 0; q < RADIX; ++q) {
-            const uint32_t nbk = s_cnt[q];
-            if (nbk != 0xffffffffu) ws.hist[(L + 1) & 1][(size_t)nbk * RADIX + d] = 0;
-        }
-        __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------- scatter --
-// M6: unstable counting-sort scatter of one tile on byte `shift/8`.  Ranks inside the
-// tile come from wave-aggregated LDS atomics (ballot match, one fetch-add per distinct
-// digit and wave -- a hot bucket costs one atomic per wave), the tile's slice of every
-// sub-bucket is reserved with one global atomic per digit (M6: inter-block order is
-// not deterministic), and the keys go through LDS so each digit run is written with
-// consecutive lanes on consecutive addresses.
-template <bool HAS_VALUES>
-__global__ __launch_bounds__(MSB_THREADS, 4) void msb_scatter_kernel(MsbWs ws, int L, const uint32_t *__restrict__ src_k,
-                                                                    uint32_t *__restrict__ dst_k,
-                                                                    const uint32_t *__restrict__ src_v,
-                                                                    uint32_t *__restrict__ dst_v, DigitSel ds, int f32_out,
-                                                                    uint32_t xor_out)
-{
-    __shared__ uint32_t scratch[8];
-    __shared__ uint32_t lcnt[RADIX], lex[RADIX], gbase[RADIX];
-    __shared__ uint32_t stage[MSB_TILE * (HAS_VALUES ? 2 : 1)];
-    __shared__ uint8_t tab[1 << SHARD_MAX_BITS];
-    load_remap(ds, tab);
-    const unsigned long long packed = ws.level[L].packed;
-    const uint32_t nb = (uint32_t)(packed >> 32), ntiles = (uint32_t)packed;
-    const int tid = threadIdx.x;
-    const MsbBucket *bk = ws.buckets[L & 1];
-    for (uint32_t g = blockIdx.x; g < ntiles; g += gridDim.x) {
-    const uint32_t b = msb_find_bucket(bk, nb, g);
-    const MsbBucket B = bk[b];
-    const uint32_t lo = B.offset + (g - B.tile_start) * MSB_TILE;
-    const uint32_t end = B.offset + B.size;
-    const uint32_t valid = (end - lo < (uint32_t)MSB_TILE) ? end - lo : (uint32_t)MSB_TILE;
+// M6: counting-sort scatter of one tile on byte `shift/8` (or on the destination rank).  The tile
+// is ranked exactly like an LSB downsweep tile (wave-striped load, wave64 ballot match +
+// wave-private LDS counters, wave 0 turns the 8 rows into bases) and finds its slice of every
+// sub-bucket from the scanned upsweep (cursor + spine + prefix16), so a level is a segmented
+// LSB pass: no global atomics (measured: the reference's scheme of one fetch-add per tile and
+// digit on the bucket's cursor row serialises on 8 cache lines and costs 2.9 ms per level at
+// 2^30 keys against 2.0 ms), and the partition is deterministic and stable.  A bucket's ragged last
+// tile pads with digit 255: the pads come last in tile order, so they land behind every real
+// key and are never stored; the upsweep never counted them.
+template <bool HAS_VALUES, bool REMAP>
+struct ScatterSmem {
+    uint32_t whist[MSB_WAVES][RADIX];                     // wave-private counters, then bases
+    uint16_t wbase[(HAS_VALUES && !REMAP) ? MSB_WAVES : 1][RADIX];   // all-wave scan only (pairs, 2 blocks/CU)
+    uint32_t gbase[RADIX];
+    uint32_t stage[MSB_TILE * (HAS_VALUES ? 2 : 1)];
+    uint8_t tab[REMAP ? (1 << SHARD_MAX_BITS) : 4];
+};
 
-    uint32_t key[MSB_KPT], val[MSB_KPT], rnk[MSB_KPT];
+template <bool HAS_VALUES, bool REMAP, bool TWOUT, bool FULL, bool BIG>
+__device__ __forceinline__ void msb_scatter_tile(ScatterSmem<HAS_VALUES, REMAP> &sm, const DigitSel &ds,
+                                                 const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ spine_c,
+                                                 uint32_t stride, const uint16_t *__restrict__ pfx,
+                                                 const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k,
+                                                 const uint32_t *__restrict__ src_v, uint32_t *__restrict__ dst_v, uint32_t lo,
+                                                 uint32_t valid, int f32_out, uint32_t xor_out)
+{
+    constexpr bool small = !BIG;                     // n <= 2^30: 32-bit byte offsets into the output
+    constexpr bool ALLWAVE = HAS_VALUES && !REMAP;   // with the 4 KiB remap table the extra rows would cost a block per CU
+    constexpr int ESH = HAS_VALUES ? 3 : 2;           // log2 of a staged element's size
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    uint32_t *my = sm.whist[w];
+    const uint16_t *mybase = sm.wbase[ALLWAVE ? w : 0];
+    const uint32_t wbase = (uint32_t)w * (WAVE * MSB_KPT) + lane;
+    uint32_t key[MSB_KPT], val[HAS_VALUES ? MSB_KPT : 1], pos[MSB_KPT];
 #pragma unroll
     for (int i = 0; i < MSB_KPT; ++i) {
-        const uint32_t idx = (uint32_t)tid + i * MSB_THREADS;
-        key[i] = (idx < valid) ? src_k[lo + idx] : 0u;
-        if (HAS_VALUES) val[i] = (idx < valid) ? src_v[lo + idx] : 0u;
+        const uint32_t idx = wbase + i * WAVE;
+        if (FULL) key[i] = src_k[lo + idx];
+        else key[i] = (idx < valid) ? src_k[lo + idx] : 0u;
     }
-    if (tid < RADIX) lcnt[tid] = 0;
-    __syncthreads();
+    if (HAS_VALUES) {
 #pragma unroll
-    for (int i = 0; i < MSB_KPT; ++i) {
-        const uint32_t idx = (uint32_t)tid + i * MSB_THREADS;
-        const bool ok = idx < valid;
-        const uint32_t d = digit_of(ds, tab, key[i]);
-        // wave-aggregated rank: the lanes holding the same digit (ballot match) take consecutive
-        // ranks from ONE fetch-add issued by the group's first lane, so a hot digit costs one LDS
-        // atomic per wave instead of 64 colliding ones
-        uint32_t plo, phi;
-        match_digit(d, plo, phi);
-        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
-        plo &= (uint32_t)okm;
-        phi &= (uint32_t)(okm >> 32);
-        const uint32_t lower = count_lower(plo, phi);
-        uint32_t base = 0;
-        if (ok && lower == 0) base = atomicAdd(&lcnt[d], (uint32_t)(__popc(plo) + __popc(phi)));
-        const int leader = plo ? __builtin_ctz(plo) : 32 + __builtin_ctz(phi | 0x80000000u);
-        rnk[i] = (uint32_t)__shfl((int)base, leader, WAVE) + lower;
-    }
-    __syncthreads();
-    {
-        const uint32_t c = (tid < RADIX) ? lcnt[tid] : 0u;
-        const uint32_t ex = block_exclusive_scan_256(c, scratch, nullptr);
-        if (tid < RADIX) {
-            const uint32_t base = c ? atomicAdd(&ws.hist[L & 1][(size_t)b * RADIX + tid], c) : 0u;
-            lex[tid] = ex;
-            gbase[tid] = base - ex;
+        for (int i = 0; i < MSB_KPT; ++i) {
+            const uint32_t idx = wbase + i * WAVE;
+            val[i] = (FULL || idx < valid) ? src_v[lo + idx] : 0u;
         }
     }
-    __syncthreads();
+    // global start of this tile's slice of every sub-bucket (wave 0): cursor + E(tile, d)
+    uint32_t tbase[4] = {0, 0, 0, 0};
+    if (w == 0) {
+        const uint4 cur = reinterpret_cast<const uint4 *>(cursor)[lane];
+        const uint32_t *sp = spine_c + (size_t)(4 * lane) * stride;
+        const uint2 pf = reinterpret_cast<const uint2 *>(pfx)[lane];
+        tbase[0] = cur.x + sp[0] + (pf.x & 0xffffu);
+        tbase[1] = cur.y + sp[stride] + (pf.x >> 16);
+        tbase[2] = cur.z + sp[2 * (size_t)stride] + (pf.y & 0xffffu);
+        tbase[3] = cur.w + sp[3 * (size_t)stride] + (pf.y >> 16);
+    }
+    auto digit = [&](uint32_t k, uint32_t idx) {
+        const uint32_t d = msb_digit<REMAP>(ds, sm.tab, k);
+        return (FULL || idx < valid) ? d : 255u;
+    };
 #pragma unroll
-    for (int i = 0; i < MSB_KPT; ++i) {
-        const uint32_t idx = (uint32_t)tid + i * MSB_THREADS;
-        if (idx < valid) {
-            const uint32_t at = lex[digit_of(ds, tab, key[i])] + rnk[i];
-            if (HAS_VALUES) reinterpret_cast<uint2 *>(stage)[at] = make_uint2(key[i], val[i]);
-            else stage[at] = key[i];
+    for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
+    {
+        uint32_t d_prev = 0, plo = 0, phi = 0;
+#pragma unroll
+        for (int i = 0; i <= MSB_KPT; ++i) {
+            uint32_t d_cur = 0, clo = 0, chi = 0;
+            if (i < MSB_KPT) {
+                d_cur = digit(key[i], wbase + i * WAVE);
+                match_digit(d_cur, clo, chi);
+            }
+            if (i > 0) {
+                const uint32_t lower = count_lower(plo, phi);
+                pos[i - 1] = my[d_prev] + lower;
+                if (lower == 0)
+                    __hip_atomic_fetch_add(&my[d_prev], (uint32_t)(__popc(plo) + __popc(phi)), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            d_prev = d_cur; plo = clo; phi = chi;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MSB_KPT; ++i) asm volatile("" : "+v"(pos[i]), "+v"(key[i]));
+    __syncthreads();
+
+    // wave 0, lane l: digits 4l..4l+3.  The tile's offsets were loaded long ago (tbase, below).
+    auto reserve = [&](const uint32_t (&ex)[4], const uint32_t (&run)[4]) {
+        (void)run;
+        uint32_t g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = small ? ((tbase[q] - ex[q]) << 2) : (tbase[q] - ex[q]);
+        reinterpret_cast<uint4 *>(sm.gbase)[lane] = make_uint4(g[0], g[1], g[2], g[3]);
+    };
+    if constexpr (ALLWAVE) {
+        uint32_t run[4] = {0, 0, 0, 0}, below[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < MSB_WAVES; ++j) {
+            const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
+            run[0] += x.x; run[1] += x.y; run[2] += x.z; run[3] += x.w;
+            if (j < w) { below[0] += x.x; below[1] += x.y; below[2] += x.z; below[3] += x.w; }
+        }
+        const uint32_t lane_sum = run[0] + run[1] + run[2] + run[3];
+        uint32_t ex[4];
+        ex[0] = wave_inclusive_scan(lane_sum) - lane_sum;
+        ex[1] = ex[0] + run[0];
+        ex[2] = ex[1] + run[1];
+        ex[3] = ex[2] + run[2];
+        reinterpret_cast<uint2 *>(sm.wbase[w])[lane] =
+            make_uint2((ex[0] + below[0]) | ((ex[1] + below[1]) << 16), (ex[2] + below[2]) | ((ex[3] + below[3]) << 16));
+        if (w == 0) reserve(ex, run);
+        // no barrier: a wave only reads its own `wbase` row, and `whist` is not written again
+    } else {
+        if (w == 0) {
+            uint32_t run[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < MSB_WAVES; ++j) {
+                const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
+                run[0] += x.x; run[1] += x.y; run[2] += x.z; run[3] += x.w;
+            }
+            const uint32_t lane_sum = run[0] + run[1] + run[2] + run[3];
+            uint32_t ex[4];
+            ex[0] = wave_inclusive_scan(lane_sum) - lane_sum;
+            ex[1] = ex[0] + run[0];
+            ex[2] = ex[1] + run[1];
+            ex[3] = ex[2] + run[2];
+            reserve(ex, run);
+            asm volatile("" ::: "memory");
+            uint4 e4 = make_uint4(ex[0] << ESH, ex[1] << ESH, ex[2] << ESH, ex[3] << ESH);   // byte offsets into `stage`
+#pragma unroll
+            for (int j = 0; j < MSB_WAVES; ++j) {
+                const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
+                reinterpret_cast<uint4 *>(sm.whist[j])[lane] = e4;
+                e4.x += x.x << ESH; e4.y += x.y << ESH; e4.z += x.z << ESH; e4.w += x.w << ESH;
+            }
+        }
+        __syncthreads();
+    }
+    {
+        uint32_t wb[MSB_KPT];
+#pragma unroll
+        for (int i = 0; i < MSB_KPT; ++i) {
+            const uint32_t d = digit(key[i], wbase + i * WAVE);
+            wb[i] = ALLWAVE ? (uint32_t)mybase[d] : my[d];
+        }
+#pragma unroll
+        for (int i = 0; i < MSB_KPT; ++i) {
+            const uint32_t at = ALLWAVE ? ((pos[i] + wb[i]) << ESH) : ((pos[i] << ESH) + wb[i]);   // bytes
+            if (HAS_VALUES) *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(sm.stage) + at) = make_uint2(key[i], val[i]);
+            else *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(sm.stage) + at) = key[i];
         }
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < MSB_KPT; ++i) {
         const uint32_t slot = (uint32_t)tid + i * MSB_THREADS;
-        if (slot < valid) {
-            uint32_t k, v = 0;
-            if (HAS_VALUES) {
-                const uint2 kv = reinterpret_cast<const uint2 *>(stage)[slot];
-                k = kv.x; v = kv.y;
+        uint32_t k, v = 0;
+        if (HAS_VALUES) {
+            const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[slot];
+            k = kv.x; v = kv.y;
+        } else {
+            k = sm.stage[slot];
+        }
+        if (FULL || slot < valid) {
+            const uint32_t gb = sm.gbase[msb_digit<REMAP>(ds, sm.tab, k)];
+            const uint32_t ko = TWOUT ? twiddle_out(k, f32_out, xor_out) : k;
+            if (small) {
+                const uint32_t off = gb + slot * 4u;
+                *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dst_k) + off) = ko;
+                if (HAS_VALUES) *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dst_v) + off) = v;
             } else {
-                k = stage[slot];
+                const uint32_t dst = gb + slot;
+                dst_k[dst] = ko;
+                if (HAS_VALUES) dst_v[dst] = v;
             }
-            const uint32_t dst = gbase[digit_of(ds, tab, k)] + slot;
-            dst_k[dst] = twiddle_out(k, f32_out, xor_out);
-            if (HAS_VALUES) dst_v[dst] = v;
         }
     }
-    __syncthreads();
+}
+
+// FULL = true: one block per level tile, dispatched in order; ragged tiles are skipped.
+// FULL = false: one block per bucket, for its ragged last tile (if any).  Two kernels keep the
+// guarded path's registers out of the hot one (as in the LSB downsweep).
+template <bool HAS_VALUES, bool REMAP, bool TWOUT, bool FULL, bool BIG>
+__global__ __launch_bounds__(MSB_THREADS, HAS_VALUES ? 4 : 6) void msb_scatter_kernel(
+    MsbWs ws, int L, const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k, const uint32_t *__restrict__ src_v,
+    uint32_t *__restrict__ dst_v, DigitSel ds, int f32_out, uint32_t xor_out)
+{
+    __shared__ __attribute__((aligned(16))) ScatterSmem<HAS_VALUES, REMAP> sm;
+    const unsigned long long packed = ws.level[L].packed;
+    uint32_t g;
+    if (FULL) {
+        if (blockIdx.x >= (uint32_t)packed) return;
+        g = tile_of_item(blockIdx.x, (uint32_t)packed);   // neighbouring tiles on one XCD: their runs meet in one L2
+    } else {
+        if (blockIdx.x >= (uint32_t)(packed >> 32)) return;
+        const MsbBucket B = ws.buckets[L & 1][blockIdx.x];
+        if (B.size % (uint32_t)MSB_TILE == 0) return;
+        g = B.tile_start + B.size / (uint32_t)MSB_TILE;
+    }
+    const MsbTile T = ws.tiles[g];
+    if (FULL && T.valid != (uint32_t)MSB_TILE) return;
+    if (REMAP) load_remap(ds, sm.tab);
+    msb_scatter_tile<HAS_VALUES, REMAP, TWOUT, FULL, BIG>(sm, ds, ws.cursors + (size_t)T.bucket * RADIX, ws.spine + g / MSB_WAVES,
+                                                          ws.stride, ws.prefix16 + (size_t)g * RADIX, src_k, dst_k, src_v, dst_v,
+                                                          T.lo, T.valid, f32_out, xor_out);
+}
+
+template <bool HAS_VALUES, bool REMAP, bool TWOUT>
+static void launch_scatter(const MsbWs &ws, int L, uint32_t tiles_ub, uint32_t buckets_ub, bool big, const uint32_t *sk, uint32_t *dk,
+                           const uint32_t *sv, uint32_t *dv, const DigitSel &ds, int f32_out, uint32_t xor_out, hipStream_t s)
+{
+    const dim3 blk(MSB_THREADS);
+    if (big) {
+        hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, REMAP, TWOUT, true, true>), dim3(tiles_ub), blk, 0, s, ws, L, sk, dk, sv, dv,
+                           ds, f32_out, xor_out);
+        hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, REMAP, TWOUT, false, true>), dim3(buckets_ub), blk, 0, s, ws, L, sk, dk, sv,
+                           dv, ds, f32_out, xor_out);
+    } else {
+        hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, REMAP, TWOUT, true, false>), dim3(tiles_ub), blk, 0, s, ws, L, sk, dk, sv, dv,
+                           ds, f32_out, xor_out);
+        hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, REMAP, TWOUT, false, false>), dim3(buckets_ub), blk, 0, s, ws, L, sk, dk, sv,
+                           dv, ds, f32_out, xor_out);
     }
 }
 
@@ -554,31 +738,11 @@ __global__ __launch_bounds__(MSB_THREADS) void shard_hist_kernel(const uint32_t 
         if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
 }
 
-__global__ void shard_counts_kernel(const uint32_t *__restrict__ row, int num_ranks, unsigned long long *__restrict__ counts)
+// per-rank counts from the single bucket's cursor row (exclusive prefix of the counts)
+__global__ void shard_counts_kernel(const uint32_t *__restrict__ row, uint32_t n, int num_ranks, unsigned long long *__restrict__ counts)
 {
-    if ((int)threadIdx.x < num_ranks) counts[threadIdx.x] = row[threadIdx.x];
-}
-
-// destination counts and scatter cursors from the bin histogram (no second pass over the keys)
-__global__ __launch_bounds__(256) void shard_cursors_kernel(const unsigned long long *__restrict__ bin_hist,
-                                                            const uint8_t *__restrict__ dest_of_bin, uint32_t nbins,
-                                                            int num_ranks, uint32_t *__restrict__ row,
-                                                            unsigned long long *__restrict__ counts)
-{
-    __shared__ uint32_t cnt[RADIX];
-    __shared__ uint32_t scratch[8];
-    const int d = threadIdx.x;
-    cnt[d] = 0;
-    __syncthreads();
-    for (uint32_t b = d; b < nbins; b += 256) {
-        const uint32_t c = (uint32_t)bin_hist[b];
-        if (c) atomicAdd(&cnt[dest_of_bin[b]], c);
-    }
-    __syncthreads();
-    const uint32_t c = cnt[d];
-    const uint32_t ex = block_exclusive_scan_256(c, scratch, nullptr);
-    row[d] = ex;
-    if (d < num_ranks) counts[d] = c;
+    const int r = threadIdx.x;
+    if (r < num_ranks) counts[r] = (unsigned long long)((r + 1 < RADIX ? row[r + 1] : n) - row[r]);
 }
 
 // ------------------------------------------------------------------- host --
@@ -671,21 +835,32 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
             // buckets at level L: <= 256 at level 1, else bounded by size; tiles: n/T + one ragged tile per bucket
             const uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
             const uint32_t max_tiles_ub = tiles_all + max_b;
-            const uint32_t max_tiles = max_tiles_ub < MSB_MAX_GRID ? max_tiles_ub : MSB_MAX_GRID;
+            // one tile per block, dispatched in order (blocks that own a long run of tiles march in
+            // lockstep and lose a third of the bandwidth, like the LSB downsweep); surplus blocks exit
+            static const char *capenv = getenv("GS_MSB_GRID_CAP");   // experiments
+            const uint32_t cap = capenv ? (uint32_t)atoi(capenv) : 0xffffffffu;
+            const uint32_t max_tiles = max_tiles_ub < cap ? max_tiles_ub : cap;
             const bool last = (L == 3);
             { KernelTimer kt(GS_K_MSB_HISTOGRAM, s);
-              hipLaunchKernelGGL(msb_hist_kernel, dim3(max_tiles), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, dsel); }
+              const uint32_t eg = max_b < 4096u ? max_b : 4096u;
+              hipLaunchKernelGGL(msb_expand_kernel, dim3(eg), dim3(256), 0, s, ws, L);
+              const uint32_t hg_ub = max_tiles_ub / MSB_WAVES + 1;                 // one block per chunk
+              const uint32_t hg = hg_ub < MSB_MAX_GRID ? hg_ub : MSB_MAX_GRID;
+              hipLaunchKernelGGL(msb_upsweep_kernel<false>, dim3(hg), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, dsel);
+              hipLaunchKernelGGL(msb_scan_kernel, dim3(RADIX), dim3(1024), 0, s, ws, L); }
             { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
               const uint32_t cg = max_b < 4096u ? max_b : 4096u;
               if (last) hipLaunchKernelGGL(msb_classify_kernel<true>, dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass);
               else hipLaunchKernelGGL(msb_classify_kernel<false>, dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass); }
             { KernelTimer kt(GS_K_MSB_PARTITION, s);
-              if (pairs)
-                  hipLaunchKernelGGL(msb_scatter_kernel<true>, dim3(max_tiles), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, dk,
-                                     (const uint32_t *)sv, dv, dsel, last ? tw.f32_out : 0, last ? tw.xor_out : 0u);
-              else
-                  hipLaunchKernelGGL(msb_scatter_kernel<false>, dim3(max_tiles), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, dk,
-                                     (const uint32_t *)nullptr, (uint32_t *)nullptr, dsel, last ? tw.f32_out : 0, last ? tw.xor_out : 0u); }
+              const bool big = num_items > (1ull << 30);
+              const uint32_t *svc = pairs ? (const uint32_t *)sv : (const uint32_t *)nullptr;
+              uint32_t *dvc = pairs ? dv : (uint32_t *)nullptr;
+#define GS_SC(HV, TW) launch_scatter<HV, false, TW>(ws, L, max_tiles, max_b, big, (const uint32_t *)sk, dk, svc, dvc, dsel, tw.f32_out, tw.xor_out, s)
+              if (pairs) { if (last) GS_SC(true, true); else GS_SC(true, false); }
+              else { if (last) GS_SC(false, true); else GS_SC(false, false); }
+#undef GS_SC
+            }
             if (!last) {
                 if (pairs) launch_local_sorts<true>(ws, L, max_tasks_lvl, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s);
                 else launch_local_sorts<false>(ws, L, max_tasks_lvl, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s);
@@ -745,27 +920,19 @@ int gs_shard_partition_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_ke
     const DigitSel dsel{0, d_dest_of_bin, 32 - bits, tw.f32_in, tw.xor_in};
     const uint32_t tiles = (n + MSB_TILE - 1) / MSB_TILE;
     const uint32_t grid = tiles;   // the tile count is known here: one tile per block, dispatched in order
+    (void)d_bin_hist;              // per-tile counts are needed now: the keys are always read once more
     KernelTimer kt(GS_K_SHARD, s);
-    // one bucket = the whole shard, "digit" = destination rank: counts -> cursors -> unstable scatter
+    // one bucket = the whole shard, "digit" = destination rank: upsweep -> scan -> cursors -> scatter
     hipLaunchKernelGGL(msb_init_kernel, dim3(1), dim3(64), 0, s, ws, n);
-    if (d_bin_hist) {
-        // the caller already has the bin histogram of these keys (gs_shard_histogram_u32)
-        hipLaunchKernelGGL(shard_cursors_kernel, dim3(1), dim3(256), 0, s, (const unsigned long long *)d_bin_hist,
-                           d_dest_of_bin, 1u << bits, num_ranks, ws.hist[0], (unsigned long long *)d_counts);
-    } else {
-        hipMemsetAsync(ws.hist[0], 0, RADIX * sizeof(uint32_t), s);
-        hipLaunchKernelGGL(msb_hist_kernel, dim3(grid), dim3(MSB_THREADS), 0, s, ws, 0, d_keys_in, dsel);
-        hipLaunchKernelGGL(shard_counts_kernel, dim3(1), dim3(RADIX), 0, s, (const uint32_t *)ws.hist[0], num_ranks,
-                           (unsigned long long *)d_counts);
-        hipLaunchKernelGGL(msb_classify_kernel<true>, dim3(1), dim3(256), 0, s, ws, 0 /* cursors only */,
-                           (const uint32_t *)nullptr, 0);
-    }
-    if (pairs)
-        hipLaunchKernelGGL(msb_scatter_kernel<true>, dim3(grid), dim3(MSB_THREADS), 0, s, ws, 0, d_keys_in, d_keys_out, d_vals_in,
-                           d_vals_out, dsel, 0, 0u);
-    else
-        hipLaunchKernelGGL(msb_scatter_kernel<false>, dim3(grid), dim3(MSB_THREADS), 0, s, ws, 0, d_keys_in, d_keys_out,
-                           (const uint32_t *)nullptr, (uint32_t *)nullptr, dsel, 0, 0u);
+    hipLaunchKernelGGL(msb_expand_kernel, dim3(1), dim3(256), 0, s, ws, 0);
+    hipLaunchKernelGGL(msb_upsweep_kernel<true>, dim3(tiles / MSB_WAVES + 1), dim3(MSB_THREADS), 0, s, ws, 0, d_keys_in, dsel);
+    hipLaunchKernelGGL(msb_scan_kernel, dim3(RADIX), dim3(1024), 0, s, ws, 0);
+    hipLaunchKernelGGL(msb_classify_kernel<true>, dim3(1), dim3(256), 0, s, ws, 0 /* cursors only */, (const uint32_t *)nullptr, 0);
+    hipLaunchKernelGGL(shard_counts_kernel, dim3(1), dim3(RADIX), 0, s, (const uint32_t *)ws.cursors, n, num_ranks,
+                       (unsigned long long *)d_counts);
+    const bool big = num_items > (1ull << 30);
+    if (pairs) launch_scatter<true, true, false>(ws, 0, grid, 1, big, d_keys_in, d_keys_out, d_vals_in, d_vals_out, dsel, 0, 0u, s);
+    else launch_scatter<false, true, false>(ws, 0, grid, 1, big, d_keys_in, d_keys_out, nullptr, nullptr, dsel, 0, 0u, s);
     return (int)hipGetLastError();
 }
 
