@@ -49,39 +49,39 @@ __device__ __forceinline__ void match_digit(uint32_t d, uint32_t &lo, uint32_t &
     asm volatile(
         "v_bfe_i32 %[t0], %[d], 0, 1\n\t"
         "v_bfe_i32 %[t1], %[d], 1, 1\n\t"
-        "v_cmp_ne_u32_e64 s[92:93], 0, %[t0]\n\t"
-        "v_cmp_ne_u32_e64 s[94:95], 0, %[t1]\n\t"
+        "v_cmp_ne_u32_e64 s[68:69], 0, %[t0]\n\t"
+        "v_cmp_ne_u32_e64 s[70:71], 0, %[t1]\n\t"
         "v_bfe_i32 %[t2], %[d], 2, 1\n\t"
-        "v_xnor_b32 %[lo], s92, %[t0]\n\t"
-        "v_xnor_b32 %[hi], s93, %[t0]\n\t"
-        "v_cmp_ne_u32_e64 s[92:93], 0, %[t2]\n\t"
-        "v_bitop3_b32 %[lo], %[lo], s94, %[t1] bitop3:0x90\n\t"
-        "v_bitop3_b32 %[hi], %[hi], s95, %[t1] bitop3:0x90\n\t"
+        "v_xnor_b32 %[lo], s68, %[t0]\n\t"
+        "v_xnor_b32 %[hi], s69, %[t0]\n\t"
+        "v_cmp_ne_u32_e64 s[68:69], 0, %[t2]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s70, %[t1] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s71, %[t1] bitop3:0x90\n\t"
         "v_bfe_i32 %[t0], %[d], 3, 1\n\t"
-        "v_cmp_ne_u32_e64 s[94:95], 0, %[t0]\n\t"
-        "v_bitop3_b32 %[lo], %[lo], s92, %[t2] bitop3:0x90\n\t"
-        "v_bitop3_b32 %[hi], %[hi], s93, %[t2] bitop3:0x90\n\t"
+        "v_cmp_ne_u32_e64 s[70:71], 0, %[t0]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s68, %[t2] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s69, %[t2] bitop3:0x90\n\t"
         "v_bfe_i32 %[t1], %[d], 4, 1\n\t"
-        "v_cmp_ne_u32_e64 s[92:93], 0, %[t1]\n\t"
-        "v_bitop3_b32 %[lo], %[lo], s94, %[t0] bitop3:0x90\n\t"
-        "v_bitop3_b32 %[hi], %[hi], s95, %[t0] bitop3:0x90\n\t"
+        "v_cmp_ne_u32_e64 s[68:69], 0, %[t1]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s70, %[t0] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s71, %[t0] bitop3:0x90\n\t"
         "v_bfe_i32 %[t2], %[d], 5, 1\n\t"
-        "v_cmp_ne_u32_e64 s[94:95], 0, %[t2]\n\t"
-        "v_bitop3_b32 %[lo], %[lo], s92, %[t1] bitop3:0x90\n\t"
-        "v_bitop3_b32 %[hi], %[hi], s93, %[t1] bitop3:0x90\n\t"
+        "v_cmp_ne_u32_e64 s[70:71], 0, %[t2]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s68, %[t1] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s69, %[t1] bitop3:0x90\n\t"
         "v_bfe_i32 %[t0], %[d], 6, 1\n\t"
-        "v_cmp_ne_u32_e64 s[92:93], 0, %[t0]\n\t"
-        "v_bitop3_b32 %[lo], %[lo], s94, %[t2] bitop3:0x90\n\t"
-        "v_bitop3_b32 %[hi], %[hi], s95, %[t2] bitop3:0x90\n\t"
+        "v_cmp_ne_u32_e64 s[68:69], 0, %[t0]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s70, %[t2] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s71, %[t2] bitop3:0x90\n\t"
         "v_bfe_i32 %[t1], %[d], 7, 1\n\t"
-        "v_cmp_ne_u32_e64 s[94:95], 0, %[t1]\n\t"
-        "v_bitop3_b32 %[lo], %[lo], s92, %[t0] bitop3:0x90\n\t"
-        "v_bitop3_b32 %[hi], %[hi], s93, %[t0] bitop3:0x90\n\t"
-        "v_bitop3_b32 %[lo], %[lo], s94, %[t1] bitop3:0x90\n\t"
-        "v_bitop3_b32 %[hi], %[hi], s95, %[t1] bitop3:0x90"
+        "v_cmp_ne_u32_e64 s[70:71], 0, %[t1]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s68, %[t0] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s69, %[t0] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s70, %[t1] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s71, %[t1] bitop3:0x90"
         : [lo] "=&v"(lo), [hi] "=&v"(hi), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
         : [d] "v"(d)
-        : "s92", "s93", "s94", "s95");
+        : "s68", "s69", "s70", "s71");
 }
 
 // rank of my lane among the set lanes of (hi:lo)

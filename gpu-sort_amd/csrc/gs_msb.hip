@@ -41,9 +41,11 @@ constexpr int MSB_TILE = MSB_THREADS * MSB_KPT;    // 8192 keys per partition ti
 constexpr int MSB_NCLASS = 4;                      // local-sort size classes (reference: 7-9 configs)
 constexpr uint32_t MSB_MERGE = 3000;               // merge adjacent sub-buckets while the sum is below this
 constexpr uint32_t MSB_MAX_GRID = 16384;           // blocks per launch; kernels stride over longer lists
-// keys per thread of each class (x 512 threads = capacity): 2048, 4608, 9216, 17408
-__host__ __device__ constexpr int msb_class_kpt(int c) { return c == 0 ? 4 : c == 1 ? 9 : c == 2 ? 18 : 34; }
-__host__ __device__ constexpr uint32_t msb_class_cap(int c) { return (uint32_t)msb_class_kpt(c) * MSB_THREADS; }
+// local-sort classes: threads x keys per thread = capacity 2048, 4608, 9216, 17408.  The two big
+// classes run 1024 threads so that two workgroups per CU give 32 waves.
+__host__ __device__ constexpr int msb_class_threads(int c) { return c < 2 ? 512 : 1024; }
+__host__ __device__ constexpr int msb_class_kpt(int c) { return c == 0 ? 4 : c == 1 ? 9 : c == 2 ? 9 : 17; }
+__host__ __device__ constexpr uint32_t msb_class_cap(int c) { return (uint32_t)(msb_class_kpt(c) * msb_class_threads(c)); }
 // pairs keep {key,value} in LDS, so their largest class is 9216 (144 KiB would not leave room for two blocks)
 __host__ __device__ constexpr int msb_num_classes(bool has_values) { return has_values ? 3 : 4; }
 
@@ -382,17 +384,17 @@ __device__ __forceinline__ void msb_scatter_tile(ScatterSmem<HAS_VALUES, REMAP> 
     const uint16_t *mybase = sm.wbase[ALLWAVE ? w : 0];
     const uint32_t wbase = (uint32_t)w * (WAVE * MSB_KPT) + lane;
     uint32_t key[MSB_KPT], val[HAS_VALUES ? MSB_KPT : 1], pos[MSB_KPT];
+    const uint32_t *pk = src_k + lo, *pv = HAS_VALUES ? src_v + lo : nullptr;   // scalar bases: loads take lane offset + immediate
 #pragma unroll
     for (int i = 0; i < MSB_KPT; ++i) {
         const uint32_t idx = wbase + i * WAVE;
-        if (FULL) key[i] = src_k[lo + idx];
-        else key[i] = (idx < valid) ? src_k[lo + idx] : 0u;
+        key[i] = pk[FULL ? idx : (idx < valid ? idx : valid - 1u)];   // clamped, never predicated (pads are masked by `digit`)
     }
     if (HAS_VALUES) {
 #pragma unroll
         for (int i = 0; i < MSB_KPT; ++i) {
             const uint32_t idx = wbase + i * WAVE;
-            val[i] = (FULL || idx < valid) ? src_v[lo + idx] : 0u;
+            val[i] = pv[FULL ? idx : (idx < valid ? idx : valid - 1u)];
         }
     }
     // global start of this tile's slice of every sub-bucket (wave 0): cursor + E(tile, d)
@@ -575,129 +577,188 @@ static void launch_scatter(const MsbWs &ws, int L, uint32_t tiles_ub, uint32_t b
 }
 
 // ------------------------------------------------------------- local sort --
-// M7: finish one range of <= KPT*512 keys inside a workgroup: LSD passes of 8 bits (the
-// first by atomic counting, the rest stable) over its low `sort_bits` bits, entirely in registers + LDS, then one coalesced
-// store to the result buffer.  Ranking per pass is the LSB downsweep's: wave64
-// ballot/popcount match + wave-private LDS histogram, wave 0 scans the 8 histograms.
-template <int KPT, bool HAS_VALUES>
+// M7: finish one range of <= THREADS*KPT keys inside a workgroup: LSD passes of 8 bits over its
+// low `sort_bits` bits, entirely in registers + LDS, then one coalesced store to the result
+// buffer.  The first pass ranks with LDS fetch-adds (nothing is ordered yet, so it need not be
+// stable -- the reference does the same, cuda_radix_sort.h:1419-1481), the later ones with the
+// LSB downsweep's wave64 ballot/popcount match.  The wave-private counters live in the staging
+// buffer itself (the keys are in registers while they are needed), so a 17408-key range costs
+// 68 KiB of LDS and two 1024-thread workgroups fit a CU.
+#ifdef GS_EXP_PHASES
+__device__ uint32_t gs_msb_phase_buf[16384 * 32];   // [block][phase] of each block's first class-3 task (experiment builds)
+#define MSB_PHASE(k)                                                                                   \
+    do {                                                                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                  \
+        if (tid == 0 && ti == blockIdx.x + 2u * gridDim.x && blockIdx.x < 16384u) gs_msb_phase_buf[blockIdx.x * 32 + (k)] += (uint32_t)(now_ - tprev_); \
+        tprev_ = now_;                                                                                 \
+    } while (0)
+#else
+#define MSB_PHASE(k) do { } while (0)
+#endif
+
+template <int THREADS, int KPT, bool HAS_VALUES>
 struct LocalSmem {
-    uint32_t whist[MSB_WAVES][RADIX];
-    uint32_t stage[KPT * MSB_THREADS * (HAS_VALUES ? 2 : 1)];
+    static constexpr int WAVES = THREADS / WAVE;
+    union {
+        uint32_t stage[KPT * THREADS * (HAS_VALUES ? 2 : 1)];
+        uint32_t whist[WAVES][RADIX];
+    };
+    uint32_t wtot[4];
 };
 
-template <int KPT, bool HAS_VALUES>
-__global__ __launch_bounds__(MSB_THREADS, 4) void msb_local_sort_kernel(MsbWs ws, int L, int cls,
-                                                                       const uint32_t *__restrict__ src_k,
-                                                                       uint32_t *__restrict__ dst_k,
-                                                                       const uint32_t *__restrict__ src_v,
-                                                                       uint32_t *__restrict__ dst_v, int f32_in,
-                                                                       uint32_t xor_in, int f32_out, uint32_t xor_out)
+template <int THREADS, int KPT, bool HAS_VALUES>
+__global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_sort_kernel(
+    MsbWs ws, int L, int cls, const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k, const uint32_t *__restrict__ src_v,
+    uint32_t *__restrict__ dst_v, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out)
 {
-    __shared__ __attribute__((aligned(16))) LocalSmem<KPT, HAS_VALUES> sm;
+    constexpr int WAVES = THREADS / WAVE;
+    static_assert(sizeof(uint32_t) * KPT * THREADS >= sizeof(uint32_t) * WAVES * RADIX, "counters must fit the staging buffer");
+    __shared__ __attribute__((aligned(16))) LocalSmem<THREADS, KPT, HAS_VALUES> sm;
     const uint32_t ntasks = ws.level[L].task_count[cls];
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     uint32_t *my = sm.whist[w];
     const uint32_t wbase = (uint32_t)w * (WAVE * KPT) + lane;
     for (uint32_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
-    const MsbTask T = ws.tasks[cls][ti];
-
-    uint32_t key[KPT], val[HAS_VALUES ? KPT : 1], pos[KPT];
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-        const uint32_t idx = wbase + i * WAVE;
-        key[i] = 0xffffffffu;                       // padding sorts last (keys are in twiddled form)
-        if (idx < T.size) key[i] = twiddle_in(src_k[T.offset + idx], f32_in, xor_in);
-        if (HAS_VALUES) val[i] = (idx < T.size) ? src_v[T.offset + idx] : 0u;
-    }
-
-    for (uint32_t shift = 0; shift < T.sort_bits; shift += 8) {
-#pragma unroll
-        for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
-        if (shift == 0) {
-            // the first LSD pass need not be stable (nothing is ordered yet; the reference does the
-            // same, cuda_radix_sort.h:1419-1481): rank = fetch-add on the wave's digit counter,
-            // one add for the whole wave when all 64 lanes hold the same digit
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                const uint32_t d = key[i] & 255u;
-                const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-                if (__builtin_amdgcn_ballot_w64(d == d0) == ~0ull) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&my[d0], 64u);
-                    pos[i] = __builtin_amdgcn_readfirstlane(base) + (uint32_t)lane;
-                } else {
-                    pos[i] = atomicAdd(&my[d], 1u);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                const uint32_t d = (key[i] >> shift) & 255u;
-                uint32_t plo, phi;
-                match_digit(d, plo, phi);
-                const uint32_t lower = count_lower(plo, phi);
-                pos[i] = my[d] + lower;
-                if (lower == 0)
-                    __hip_atomic_fetch_add(&my[d], (uint32_t)(__popc(plo) + __popc(phi)), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]), "+v"(key[i]));
-        __syncthreads();
-        if (w == 0) {
-            uint32_t run[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < MSB_WAVES; ++j) {
-                const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
-                run[0] += x.x; run[1] += x.y; run[2] += x.z; run[3] += x.w;
-            }
-            const uint32_t lane_sum = run[0] + run[1] + run[2] + run[3];
-            uint4 e4;
-            e4.x = wave_inclusive_scan(lane_sum) - lane_sum;
-            e4.y = e4.x + run[0];
-            e4.z = e4.y + run[1];
-            e4.w = e4.z + run[2];
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < MSB_WAVES; ++j) {
-                const uint4 x = reinterpret_cast<const uint4 *>(sm.whist[j])[lane];
-                reinterpret_cast<uint4 *>(sm.whist[j])[lane] = e4;
-                e4.x += x.x; e4.y += x.y; e4.z += x.z; e4.w += x.w;
-            }
-        }
-        __syncthreads();
+        const MsbTask T = ws.tasks[cls][ti];
+#ifdef GS_EXP_PHASES
+        unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+        if (tid < 32 && ti == blockIdx.x + 2u * gridDim.x && blockIdx.x < 16384u) gs_msb_phase_buf[blockIdx.x * 32 + tid] = 0;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        MSB_PHASE(20);                                    // task record + drain of the previous task's stores
+#endif
+        uint32_t key[KPT], val[HAS_VALUES ? KPT : 1], pos[KPT];
+        const uint32_t *pk = src_k + T.offset, *pv = HAS_VALUES ? src_v + T.offset : nullptr;   // scalar bases
+        // unconditional loads from clamped indices (a predicated load waits for its data before the
+        // next one is issued: 17 round trips instead of one), padding applied afterwards
+        const uint32_t last = T.size - 1u;
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            const uint32_t at = pos[i] + my[(key[i] >> shift) & 255u];
-            if (HAS_VALUES) reinterpret_cast<uint2 *>(sm.stage)[at] = make_uint2(key[i], val[i]);
-            else sm.stage[at] = key[i];
+            const uint32_t idx = wbase + i * WAVE;
+            key[i] = pk[idx < last ? idx : last];
+            if (HAS_VALUES) val[i] = pv[idx < last ? idx : last];
         }
-        __syncthreads();
-        if (shift + 8 < T.sort_bits) {
 #pragma unroll
-            for (int i = 0; i < KPT; ++i) {
-                const uint32_t idx = wbase + i * WAVE;
-                if (HAS_VALUES) {
-                    const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[idx];
-                    key[i] = kv.x; val[i] = kv.y;
-                } else {
-                    key[i] = sm.stage[idx];
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = wbase + i * WAVE;
+            const uint32_t k = twiddle_in(key[i], f32_in, xor_in);
+            key[i] = (idx < T.size) ? k : 0xffffffffu;  // padding sorts last (keys are in twiddled form)
+        }
+        MSB_PHASE(21);                                    // load issue
+#ifdef GS_EXP_PHASES
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        MSB_PHASE(0);                                     // load wait
+        for (uint32_t shift = 0; shift < T.sort_bits; shift += 8) {
+            const int pb_ = shift ? 8 : 1;                // phase slots 1..6 first pass, 8..13 later passes
+            (void)pb_;
+            if (shift != 0) {
+                // back into registers in position order; then the counters may overwrite the buffer
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    const uint32_t idx = wbase + i * WAVE;
+                    if (HAS_VALUES) {
+                        const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[idx];
+                        key[i] = kv.x; val[i] = kv.y;
+                    } else {
+                        key[i] = sm.stage[idx];
+                    }
+                }
+                __syncthreads();
+            }
+            MSB_PHASE(pb_ + 0);                           // readback + barrier
+#pragma unroll
+            for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
+            if (shift == 0) {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    const uint32_t d = key[i] & 255u;
+                    const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+                    if (__builtin_amdgcn_ballot_w64(d == d0) == ~0ull) {       // one add for a wave-uniform digit
+                        const uint32_t base = my[d0];
+                        if (lane == 0) my[d0] = base + 64u;
+                        pos[i] = base + (uint32_t)lane;
+                    } else {
+                        pos[i] = atomicAdd(&my[d], 1u);
+                    }
+                }
+            } else {
+                uint32_t d_prev = 0, plo = 0, phi = 0;
+#pragma unroll
+                for (int i = 0; i <= KPT; ++i) {
+                    uint32_t d_cur = 0, clo = 0, chi = 0;
+                    if (i < KPT) {
+                        d_cur = __builtin_amdgcn_ubfe(key[i], shift, 8u);
+                        match_digit(d_cur, clo, chi);
+                    }
+                    if (i > 0) {
+                        const uint32_t lower = count_lower(plo, phi);
+                        pos[i - 1] = my[d_prev] + lower;
+                        if (lower == 0)
+                            __hip_atomic_fetch_add(&my[d_prev], (uint32_t)(__popc(plo) + __popc(phi)), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+                    d_prev = d_cur; plo = clo; phi = chi;
                 }
             }
-            // the next pass rewrites `stage` only after its two barriers
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]), "+v"(key[i]));
+#ifdef GS_EXP_PHASES
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            MSB_PHASE(pb_ + 1);                           // rank
+            __syncthreads();
+            MSB_PHASE(pb_ + 2);                           // barrier after rank
+            // digit-parallel scan by the first 256 threads: per digit, exclusive prefix over the waves'
+            // counts (in place), then the exclusive scan of the digit totals folded into every row
+            uint32_t tot = 0, inc = 0;
+            if (tid < RADIX) {
+#pragma unroll
+                for (int j = 0; j < WAVES; ++j) {
+                    const uint32_t c = sm.whist[j][tid];
+                    sm.whist[j][tid] = tot;
+                    tot += c;
+                }
+                inc = wave_inclusive_scan(tot);
+                if (lane == 63) sm.wtot[w] = inc;
+            }
+            __syncthreads();
+            if (tid < RADIX) {
+                uint32_t ex = inc - tot;
+                if (w > 0) ex += sm.wtot[0];
+                if (w > 1) ex += sm.wtot[1];
+                if (w > 2) ex += sm.wtot[2];
+#pragma unroll
+                for (int j = 0; j < WAVES; ++j) sm.whist[j][tid] += ex;
+            }
+            __syncthreads();
+            MSB_PHASE(pb_ + 3);                           // scan (2 barriers)
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) pos[i] += my[__builtin_amdgcn_ubfe(key[i], shift, 8u)];
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]));
+            __syncthreads();                              // the counters are dead: the buffer takes the keys
+            MSB_PHASE(pb_ + 4);                           // base lookup + barrier
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                if (HAS_VALUES) reinterpret_cast<uint2 *>(sm.stage)[pos[i]] = make_uint2(key[i], val[i]);
+                else sm.stage[pos[i]] = key[i];
+            }
+            __syncthreads();
+            MSB_PHASE(pb_ + 5);                           // LDS scatter + barrier
         }
-    }
-    for (uint32_t j = tid; j < T.size; j += MSB_THREADS) {
-        if (HAS_VALUES) {
-            const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[j];
-            dst_k[T.offset + j] = twiddle_out(kv.x, f32_out, xor_out);
-            dst_v[T.offset + j] = kv.y;
-        } else {
-            dst_k[T.offset + j] = twiddle_out(sm.stage[j], f32_out, xor_out);
+        uint32_t *qk = dst_k + T.offset, *qv = HAS_VALUES ? dst_v + T.offset : nullptr;
+        for (uint32_t j = tid; j < T.size; j += THREADS) {
+            if (HAS_VALUES) {
+                const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[j];
+                qk[j] = twiddle_out(kv.x, f32_out, xor_out);
+                qv[j] = kv.y;
+            } else {
+                qk[j] = twiddle_out(sm.stage[j], f32_out, xor_out);
+            }
         }
-    }
-    __syncthreads();
+        MSB_PHASE(16);                                    // store issue
+        __syncthreads();
+        MSB_PHASE(17);                                    // final barrier
     }
 }
 
@@ -752,17 +813,14 @@ static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uin
                                uint32_t *dv, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out, hipStream_t s)
 {
     KernelTimer kt(GS_K_MSB_LOCAL_SORT, s);
-    const dim3 block(MSB_THREADS);
     const uint32_t grid = bound < MSB_MAX_GRID ? bound : MSB_MAX_GRID;   // grid-stride over the task list
-    hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_kpt(0), HAS_VALUES>), dim3(grid), block, 0, s, ws, L, 0, sk, dk, sv,
-                       dv, f32_in, xor_in, f32_out, xor_out);
-    hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_kpt(1), HAS_VALUES>), dim3(grid), block, 0, s, ws, L, 1, sk, dk, sv,
-                       dv, f32_in, xor_in, f32_out, xor_out);
-    hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_kpt(2), HAS_VALUES>), dim3(grid), block, 0, s, ws, L, 2, sk, dk, sv,
-                       dv, f32_in, xor_in, f32_out, xor_out);
-    if (!HAS_VALUES)
-        hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_kpt(3), false>), dim3(grid), block, 0, s, ws, L, 3, sk, dk, sv,
-                           dv, f32_in, xor_in, f32_out, xor_out);
+#define GS_LS(C, HV) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV>), dim3(grid), \
+                                        dim3(msb_class_threads(C)), 0, s, ws, L, C, sk, dk, sv, dv, f32_in, xor_in, f32_out, xor_out)
+    GS_LS(0, HAS_VALUES);
+    GS_LS(1, HAS_VALUES);
+    GS_LS(2, HAS_VALUES);
+    if (!HAS_VALUES) GS_LS(3, false);
+#undef GS_LS
 }
 
 }  // namespace gs
@@ -770,6 +828,13 @@ static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uin
 using namespace gs;
 
 extern "C" {
+
+#ifdef GS_EXP_PHASES
+int gs_exp_msb_phases(uint32_t *host_out, uint32_t blocks)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(gs_msb_phase_buf), (size_t)blocks * 32 * sizeof(uint32_t));
+}
+#endif
 
 size_t gs_msb_temp_bytes(uint64_t num_items, int has_values)
 {

@@ -121,10 +121,18 @@ __global__ __launch_bounds__(W_THREADS, 4) void wide_downsweep_kernel(const K *_
     K key[W_KPT];
     uint32_t pos[W_KPT];
     const K pad = (K)~(K)0;                     // twiddled all-ones: largest digit, ranked last
+    // unconditional loads from clamped indices (predicated loads are issued one round trip at a time)
+    const K *kin = keys_in + tile_base;
 #pragma unroll
     for (int i = 0; i < W_KPT; ++i) {
         const uint32_t idx = wbase + i * WAVE;
-        key[i] = (idx < valid) ? w_twiddle_in<K>(keys_in[tile_base + idx], p.f_in, p.xor_in) : pad;
+        key[i] = kin[idx < valid ? idx : valid - 1u];
+    }
+#pragma unroll
+    for (int i = 0; i < W_KPT; ++i) {
+        const uint32_t idx = wbase + i * WAVE;
+        const K k = w_twiddle_in<K>(key[i], p.f_in, p.xor_in);
+        key[i] = (idx < valid) ? k : pad;
     }
 #pragma unroll
     for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
@@ -181,10 +189,11 @@ __global__ __launch_bounds__(W_THREADS, 4) void wide_downsweep_kernel(const K *_
     if constexpr (HAS_VALUES) {
         V *stage_v = reinterpret_cast<V *>(stage_raw);
         V val[W_KPT];
+        const V *vin = vals_in + tile_base;
 #pragma unroll
         for (int i = 0; i < W_KPT; ++i) {
             const uint32_t idx = wbase + i * WAVE;
-            val[i] = (idx < valid) ? vals_in[tile_base + idx] : V(0);
+            val[i] = vin[idx < valid ? idx : valid - 1u];
         }
         __syncthreads();                       // everyone is done reading the keys
 #pragma unroll
