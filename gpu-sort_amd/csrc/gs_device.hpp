@@ -84,6 +84,79 @@ __device__ __forceinline__ void match_digit(uint32_t d, uint32_t &lo, uint32_t &
         : "s68", "s69", "s70", "s71");
 }
 
+// the same for digits below 32 (5 ballots, 20 instructions): local-sort passes on few bits
+__device__ __forceinline__ void match_digit5(uint32_t d, uint32_t &lo, uint32_t &hi)
+{
+    uint32_t t0, t1, t2;
+    asm volatile(
+        "v_bfe_i32 %[t0], %[d], 0, 1\n\t"
+        "v_bfe_i32 %[t1], %[d], 1, 1\n\t"
+        "v_cmp_ne_u32_e64 s[68:69], 0, %[t0]\n\t"
+        "v_cmp_ne_u32_e64 s[70:71], 0, %[t1]\n\t"
+        "v_bfe_i32 %[t2], %[d], 2, 1\n\t"
+        "v_xnor_b32 %[lo], s68, %[t0]\n\t"
+        "v_xnor_b32 %[hi], s69, %[t0]\n\t"
+        "v_cmp_ne_u32_e64 s[68:69], 0, %[t2]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s70, %[t1] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s71, %[t1] bitop3:0x90\n\t"
+        "v_bfe_i32 %[t0], %[d], 3, 1\n\t"
+        "v_cmp_ne_u32_e64 s[70:71], 0, %[t0]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s68, %[t2] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s69, %[t2] bitop3:0x90\n\t"
+        "v_bfe_i32 %[t1], %[d], 4, 1\n\t"
+        "v_cmp_ne_u32_e64 s[68:69], 0, %[t1]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s70, %[t0] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s71, %[t0] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s68, %[t1] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s69, %[t1] bitop3:0x90"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+        : [d] "v"(d)
+        : "s68", "s69", "s70", "s71");
+}
+
+// digits below 16 (4 ballots, 16 instructions) and below 4 (2 ballots, 8 instructions)
+__device__ __forceinline__ void match_digit4(uint32_t d, uint32_t &lo, uint32_t &hi)
+{
+    uint32_t t0, t1, t2;
+    asm volatile(
+        "v_bfe_i32 %[t0], %[d], 0, 1\n\t"
+        "v_bfe_i32 %[t1], %[d], 1, 1\n\t"
+        "v_cmp_ne_u32_e64 s[68:69], 0, %[t0]\n\t"
+        "v_cmp_ne_u32_e64 s[70:71], 0, %[t1]\n\t"
+        "v_bfe_i32 %[t2], %[d], 2, 1\n\t"
+        "v_xnor_b32 %[lo], s68, %[t0]\n\t"
+        "v_xnor_b32 %[hi], s69, %[t0]\n\t"
+        "v_cmp_ne_u32_e64 s[68:69], 0, %[t2]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s70, %[t1] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s71, %[t1] bitop3:0x90\n\t"
+        "v_bfe_i32 %[t0], %[d], 3, 1\n\t"
+        "v_cmp_ne_u32_e64 s[70:71], 0, %[t0]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s68, %[t2] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s69, %[t2] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s70, %[t0] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s71, %[t0] bitop3:0x90"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+        : [d] "v"(d)
+        : "s68", "s69", "s70", "s71");
+}
+__device__ __forceinline__ void match_digit2(uint32_t d, uint32_t &lo, uint32_t &hi)
+{
+    uint32_t t0, t1;
+    asm volatile(
+        "v_bfe_i32 %[t0], %[d], 0, 1\n\t"
+        "v_bfe_i32 %[t1], %[d], 1, 1\n\t"
+        "v_cmp_ne_u32_e64 s[68:69], 0, %[t0]\n\t"
+        "v_cmp_ne_u32_e64 s[70:71], 0, %[t1]\n\t"
+        "s_nop 0\n\t"
+        "v_xnor_b32 %[lo], s68, %[t0]\n\t"
+        "v_xnor_b32 %[hi], s69, %[t0]\n\t"
+        "v_bitop3_b32 %[lo], %[lo], s70, %[t1] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[hi], %[hi], s71, %[t1] bitop3:0x90"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        : [d] "v"(d)
+        : "s68", "s69", "s70", "s71");
+}
+
 // rank of my lane among the set lanes of (hi:lo)
 __device__ __forceinline__ uint32_t count_lower(uint32_t lo, uint32_t hi)
 {

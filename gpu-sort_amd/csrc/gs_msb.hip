@@ -388,13 +388,15 @@ __device__ __forceinline__ void msb_scatter_tile(ScatterSmem<HAS_VALUES, REMAP> 
 #pragma unroll
     for (int i = 0; i < MSB_KPT; ++i) {
         const uint32_t idx = wbase + i * WAVE;
-        key[i] = pk[FULL ? idx : (idx < valid ? idx : valid - 1u)];   // clamped, never predicated (pads are masked by `digit`)
+        const uint32_t off = (FULL ? idx : (idx < valid ? idx : valid - 1u)) * 4u;   // clamped, never predicated (pads are masked by `digit`)
+        key[i] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(pk) + off);
     }
     if (HAS_VALUES) {
 #pragma unroll
         for (int i = 0; i < MSB_KPT; ++i) {
             const uint32_t idx = wbase + i * WAVE;
-            val[i] = pv[FULL ? idx : (idx < valid ? idx : valid - 1u)];
+            const uint32_t off = (FULL ? idx : (idx < valid ? idx : valid - 1u)) * 4u;
+            val[i] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(pv) + off);
         }
     }
     // global start of this tile's slice of every sub-bucket (wave 0): cursor + E(tile, d)
@@ -584,111 +586,184 @@ static void launch_scatter(const MsbWs &ws, int L, uint32_t tiles_ub, uint32_t b
 // LSB downsweep's wave64 ballot/popcount match.  The wave-private counters live in the staging
 // buffer itself (the keys are in registers while they are needed), so a 17408-key range costs
 // 68 KiB of LDS and two 1024-thread workgroups fit a CU.
-#ifdef GS_EXP_PHASES
-__device__ uint32_t gs_msb_phase_buf[16384 * 32];   // [block][phase] of each block's first class-3 task (experiment builds)
-#define MSB_PHASE(k)                                                                                   \
-    do {                                                                                               \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                  \
-        if (tid == 0 && ti == blockIdx.x + 2u * gridDim.x && blockIdx.x < 16384u) gs_msb_phase_buf[blockIdx.x * 32 + (k)] += (uint32_t)(now_ - tprev_); \
-        tprev_ = now_;                                                                                 \
-    } while (0)
-#else
-#define MSB_PHASE(k) do { } while (0)
-#endif
-
+// digit width of the first (order-free) local pass: about one bin per key, and the histogram fits
+// the staging buffer it is overlaid on (2048 -> 11, 4608 -> 12, 9216 -> 13, 17408 -> 14 bits)
+__host__ __device__ constexpr int local_b1(int cap) { return cap >= 16384 ? 14 : cap >= 8192 ? 13 : cap >= 4096 ? 12 : 11; }
 template <int THREADS, int KPT, bool HAS_VALUES>
 struct LocalSmem {
     static constexpr int WAVES = THREADS / WAVE;
     union {
         uint32_t stage[KPT * THREADS * (HAS_VALUES ? 2 : 1)];
-        uint32_t whist[WAVES][RADIX];
+        uint32_t hist[1 << local_b1(KPT * THREADS)];   // first pass: one shared histogram
+        uint32_t whist[WAVES][RADIX];        // later passes: wave-private counters
     };
-    uint32_t wtot[4];
+    uint32_t wtot[16];
 };
 
+// M7, one pass plan per task (B = sort_bits): the first pass takes min(B, 11..14) bits and ranks with LDS
+// fetch-adds on ONE shared histogram (nothing is ordered yet, so it need not be stable -- the
+// reference does the same, cuda_radix_sort.h:1419-1481); the remaining bits go in stable passes of
+// at most 8 bits ranked by the wave64 ballot match with as many ballots as the digit has bits (a
+// 16-bit task of the largest class is 14 + 2).  Counters and histogram live in the staging buffer itself (the
+// keys are in registers while they are needed), so a 17408-key range costs 68 KiB of LDS and two
+// 1024-thread workgroups fit a CU.  The next task's keys are requested before the current one is
+// stored (their registers are free by then).
 template <int THREADS, int KPT, bool HAS_VALUES>
 __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_sort_kernel(
     MsbWs ws, int L, int cls, const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k, const uint32_t *__restrict__ src_v,
     uint32_t *__restrict__ dst_v, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out)
 {
     constexpr int WAVES = THREADS / WAVE;
-    static_assert(sizeof(uint32_t) * KPT * THREADS >= sizeof(uint32_t) * WAVES * RADIX, "counters must fit the staging buffer");
+    constexpr int LOCAL_B1 = local_b1(KPT * THREADS);
+    static_assert(KPT * THREADS >= (1 << LOCAL_B1) && KPT * THREADS >= WAVES * RADIX, "counters must fit the staging buffer");
     __shared__ __attribute__((aligned(16))) LocalSmem<THREADS, KPT, HAS_VALUES> sm;
     const uint32_t ntasks = ws.level[L].task_count[cls];
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     uint32_t *my = sm.whist[w];
-    const uint32_t wbase = (uint32_t)w * (WAVE * KPT) + lane;
-    for (uint32_t ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
-        const MsbTask T = ws.tasks[cls][ti];
-#ifdef GS_EXP_PHASES
-        unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
-        if (tid < 32 && ti == blockIdx.x + 2u * gridDim.x && blockIdx.x < 16384u) gs_msb_phase_buf[blockIdx.x * 32 + tid] = 0;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        MSB_PHASE(20);                                    // task record + drain of the previous task's stores
-#endif
-        uint32_t key[KPT], val[HAS_VALUES ? KPT : 1], pos[KPT];
-        const uint32_t *pk = src_k + T.offset, *pv = HAS_VALUES ? src_v + T.offset : nullptr;   // scalar bases
-        // unconditional loads from clamped indices (a predicated load waits for its data before the
-        // next one is issued: 17 round trips instead of one), padding applied afterwards
-        const uint32_t last = T.size - 1u;
+    const uint32_t wbase0 = (uint32_t)w * (WAVE * KPT) + lane;
+    // every use site takes a fresh, opaque copy of a cheap index base: otherwise the compiler keeps all
+    // KPT derived indices and addresses live across the task loop and spills them (64-VGPR budget)
+    auto fresh = [](uint32_t x) { asm volatile("" : "+v"(x)); return x; };
+    uint32_t ti = blockIdx.x;
+    if (ti >= ntasks) return;
+    MsbTask T = ws.tasks[cls][ti];
+    uint32_t key[KPT], val[HAS_VALUES ? KPT : 1], pos[KPT];
+    // unconditional loads from clamped indices (a predicated load waits for its data before the
+    // next one is issued: KPT round trips instead of one); padding is applied afterwards
+    auto request = [&](const MsbTask &t) {
+        const uint32_t *pk = src_k + t.offset, *pv = HAS_VALUES ? src_v + t.offset : nullptr;   // scalar bases
+        const uint32_t last = t.size - 1u;
+        const uint32_t wbase = fresh(wbase0);
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const uint32_t idx = wbase + i * WAVE;
-            key[i] = pk[idx < last ? idx : last];
-            if (HAS_VALUES) val[i] = pv[idx < last ? idx : last];
+            const uint32_t off = (idx < last ? idx : last) * 4u;      // 32-bit byte offset: scalar base + vector offset
+            key[i] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(pk) + off);
+            if (HAS_VALUES) val[i] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(pv) + off);
         }
+    };
+    request(T);
+    for (;;) {
+        const uint32_t tn = ti + gridDim.x;
+        const bool has_next = tn < ntasks;
+        const MsbTask Tn = ws.tasks[cls][has_next ? tn : ti];
+        {
+            const uint32_t wbase = fresh(wbase0);
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const uint32_t idx = wbase + i * WAVE;
-            const uint32_t k = twiddle_in(key[i], f32_in, xor_in);
-            key[i] = (idx < T.size) ? k : 0xffffffffu;  // padding sorts last (keys are in twiddled form)
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t idx = wbase + i * WAVE;
+                const uint32_t k = twiddle_in(key[i], f32_in, xor_in);
+                key[i] = (idx < T.size) ? k : 0xffffffffu;   // padding sorts last (keys are in twiddled form)
+            }
         }
-        MSB_PHASE(21);                                    // load issue
-#ifdef GS_EXP_PHASES
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        MSB_PHASE(0);                                     // load wait
-        for (uint32_t shift = 0; shift < T.sort_bits; shift += 8) {
-            const int pb_ = shift ? 8 : 1;                // phase slots 1..6 first pass, 8..13 later passes
-            (void)pb_;
-            if (shift != 0) {
-                // back into registers in position order; then the counters may overwrite the buffer
+        const uint32_t B = T.sort_bits;
+        const uint32_t b1 = B < (uint32_t)LOCAL_B1 ? B : (uint32_t)LOCAL_B1;
+        {   // ---- first pass: shared histogram of 2^b1 bins, order-free ranks
+            const uint32_t nbins = 1u << b1, mask1 = nbins - 1u;
+            for (uint32_t j = tid; j < nbins; j += THREADS) sm.hist[j] = 0;
+            __syncthreads();
+            // the pads take no part in this pass (an order-free rank could put one in front of a real key
+            // with all-ones digits): real keys fill [0, size), the pads stay implicit behind them
+            {
+                const uint32_t wbase = fresh(wbase0);
 #pragma unroll
                 for (int i = 0; i < KPT; ++i) {
-                    const uint32_t idx = wbase + i * WAVE;
-                    if (HAS_VALUES) {
-                        const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[idx];
-                        key[i] = kv.x; val[i] = kv.y;
-                    } else {
-                        key[i] = sm.stage[idx];
+                    pos[i] = 0;
+                    if (wbase + i * WAVE < T.size) {
+                        const uint32_t d = key[i] & mask1;
+                        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+                        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+                        if (__builtin_amdgcn_ballot_w64(d == d0) == act) {      // one add for a wave-uniform digit
+                            const uint32_t lower = count_lower_mask(act);
+                            uint32_t base = 0;
+                            if (lower == 0) base = atomicAdd(&sm.hist[d0], (uint32_t)__popcll(act));
+                            pos[i] = __builtin_amdgcn_readfirstlane(base) + lower;
+                        } else {
+                            pos[i] = atomicAdd(&sm.hist[d], 1u);
+                        }
                     }
                 }
-                __syncthreads();
             }
-            MSB_PHASE(pb_ + 0);                           // readback + barrier
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]), "+v"(key[i]));
+            __syncthreads();
+            // exclusive scan of the bins in place: IPT consecutive bins per thread (fewer bins: fewer threads)
+            constexpr uint32_t IPT = (1u << LOCAL_B1) / THREADS;
+            const bool act = (uint32_t)tid * IPT < nbins;
+            uint32_t ssum = 0;
+            if (act) {
+#pragma unroll
+                for (uint32_t q = 0; q < IPT; q += 4) {
+                    const uint4 c4 = reinterpret_cast<const uint4 *>(sm.hist)[((uint32_t)tid * IPT + q) >> 2];
+                    ssum += c4.x + c4.y + c4.z + c4.w;
+                }
+            }
+            const uint32_t inc = wave_inclusive_scan(ssum);
+            if (lane == 63) sm.wtot[w] = inc;
+            __syncthreads();
+            const uint32_t wsv = (lane < WAVES) ? sm.wtot[lane] : 0u;
+            const uint32_t wincl = wave_inclusive_scan(wsv);
+            uint32_t run = (uint32_t)__shfl((int)(wincl - wsv), w, WAVE) + inc - ssum;
+            if (act) {
+#pragma unroll
+                for (uint32_t q = 0; q < IPT; q += 4) {
+                    uint4 *p4 = reinterpret_cast<uint4 *>(sm.hist) + (((uint32_t)tid * IPT + q) >> 2);
+                    const uint4 c4 = *p4;
+                    uint4 e4;
+                    e4.x = run; e4.y = e4.x + c4.x; e4.z = e4.y + c4.y; e4.w = e4.z + c4.z;
+                    run = e4.w + c4.w;
+                    *p4 = e4;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) pos[i] += sm.hist[key[i] & mask1];
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]));
+            __syncthreads();                              // the histogram is dead: the buffer takes the keys
+            {
+                const uint32_t wbase = fresh(wbase0);
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    if (wbase + i * WAVE < T.size) {
+                        if (HAS_VALUES) reinterpret_cast<uint2 *>(sm.stage)[pos[i]] = make_uint2(key[i], val[i]);
+                        else sm.stage[pos[i]] = key[i];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- remaining bits: stable passes of <= 8 bits
+        uint32_t rem = B - b1, np = (rem + 7u) / 8u, shift = b1;
+        while (rem) {
+            const uint32_t b = (rem + np - 1u) / np, nd = 1u << b;
+            const uint32_t wbase = fresh(wbase0);
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {               // back into registers in position order
+                const uint32_t idx = wbase + i * WAVE;
+                if (HAS_VALUES) {
+                    const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[idx];
+                    key[i] = kv.x; val[i] = kv.y;
+                } else {
+                    key[i] = sm.stage[idx];
+                }
+                if (idx >= T.size) key[i] = 0xffffffffu;  // the pads: last in position and largest in every digit
+            }
+            __syncthreads();                              // then the counters may overwrite the buffer
 #pragma unroll
             for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
-            if (shift == 0) {
-#pragma unroll
-                for (int i = 0; i < KPT; ++i) {
-                    const uint32_t d = key[i] & 255u;
-                    const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-                    if (__builtin_amdgcn_ballot_w64(d == d0) == ~0ull) {       // one add for a wave-uniform digit
-                        const uint32_t base = my[d0];
-                        if (lane == 0) my[d0] = base + 64u;
-                        pos[i] = base + (uint32_t)lane;
-                    } else {
-                        pos[i] = atomicAdd(&my[d], 1u);
-                    }
-                }
-            } else {
+            auto rank_pass = [&](auto width) {
                 uint32_t d_prev = 0, plo = 0, phi = 0;
 #pragma unroll
                 for (int i = 0; i <= KPT; ++i) {
                     uint32_t d_cur = 0, clo = 0, chi = 0;
                     if (i < KPT) {
-                        d_cur = __builtin_amdgcn_ubfe(key[i], shift, 8u);
-                        match_digit(d_cur, clo, chi);
+                        d_cur = __builtin_amdgcn_ubfe(key[i], shift, b);
+                        constexpr int MB = decltype(width)::value;
+                        if (MB == 2) match_digit2(d_cur, clo, chi);
+                        else if (MB == 4) match_digit4(d_cur, clo, chi);
+                        else if (MB == 5) match_digit5(d_cur, clo, chi);
+                        else match_digit(d_cur, clo, chi);
                     }
                     if (i > 0) {
                         const uint32_t lower = count_lower(plo, phi);
@@ -699,30 +774,31 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
                     }
                     d_prev = d_cur; plo = clo; phi = chi;
                 }
-            }
+            };
+            if (b <= 2u) rank_pass(std::integral_constant<int, 2>{});
+            else if (b <= 4u) rank_pass(std::integral_constant<int, 4>{});
+            else if (b <= 5u) rank_pass(std::integral_constant<int, 5>{});
+            else rank_pass(std::integral_constant<int, 8>{});
 #pragma unroll
             for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]), "+v"(key[i]));
-#ifdef GS_EXP_PHASES
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-            MSB_PHASE(pb_ + 1);                           // rank
             __syncthreads();
-            MSB_PHASE(pb_ + 2);                           // barrier after rank
             // digit-parallel scan by the first 256 threads: per digit, exclusive prefix over the waves'
             // counts (in place), then the exclusive scan of the digit totals folded into every row
             uint32_t tot = 0, inc = 0;
-            if (tid < RADIX) {
+            if ((uint32_t)tid < nd) {
 #pragma unroll
                 for (int j = 0; j < WAVES; ++j) {
                     const uint32_t c = sm.whist[j][tid];
                     sm.whist[j][tid] = tot;
                     tot += c;
                 }
+            }
+            if (tid < RADIX) {
                 inc = wave_inclusive_scan(tot);
                 if (lane == 63) sm.wtot[w] = inc;
             }
             __syncthreads();
-            if (tid < RADIX) {
+            if ((uint32_t)tid < nd) {
                 uint32_t ex = inc - tot;
                 if (w > 0) ex += sm.wtot[0];
                 if (w > 1) ex += sm.wtot[1];
@@ -731,34 +807,41 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
                 for (int j = 0; j < WAVES; ++j) sm.whist[j][tid] += ex;
             }
             __syncthreads();
-            MSB_PHASE(pb_ + 3);                           // scan (2 barriers)
 #pragma unroll
-            for (int i = 0; i < KPT; ++i) pos[i] += my[__builtin_amdgcn_ubfe(key[i], shift, 8u)];
+            for (int i = 0; i < KPT; ++i) pos[i] += my[__builtin_amdgcn_ubfe(key[i], shift, b)];
 #pragma unroll
             for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]));
             __syncthreads();                              // the counters are dead: the buffer takes the keys
-            MSB_PHASE(pb_ + 4);                           // base lookup + barrier
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 if (HAS_VALUES) reinterpret_cast<uint2 *>(sm.stage)[pos[i]] = make_uint2(key[i], val[i]);
                 else sm.stage[pos[i]] = key[i];
             }
             __syncthreads();
-            MSB_PHASE(pb_ + 5);                           // LDS scatter + barrier
+            shift += b; rem -= b; --np;
         }
+        // ---- request the next task's keys, then store this one from the buffer
+        if (has_next) request(Tn);
         uint32_t *qk = dst_k + T.offset, *qv = HAS_VALUES ? dst_v + T.offset : nullptr;
-        for (uint32_t j = tid; j < T.size; j += THREADS) {
-            if (HAS_VALUES) {
+        if (HAS_VALUES) {
+            for (uint32_t j = tid; j < T.size; j += THREADS) {
                 const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[j];
                 qk[j] = twiddle_out(kv.x, f32_out, xor_out);
                 qv[j] = kv.y;
-            } else {
-                qk[j] = twiddle_out(sm.stage[j], f32_out, xor_out);
+            }
+        } else {
+            const uint32_t t0 = fresh((uint32_t)tid);
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) pos[i] = sm.stage[t0 + i * THREADS];   // `pos` is free: batch the reads
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t j = t0 + i * THREADS;
+                if (j < T.size) *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(qk) + j * 4u) = twiddle_out(pos[i], f32_out, xor_out);
             }
         }
-        MSB_PHASE(16);                                    // store issue
         __syncthreads();
-        MSB_PHASE(17);                                    // final barrier
+        if (!has_next) break;
+        T = Tn; ti = tn;
     }
 }
 
@@ -828,13 +911,6 @@ static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uin
 using namespace gs;
 
 extern "C" {
-
-#ifdef GS_EXP_PHASES
-int gs_exp_msb_phases(uint32_t *host_out, uint32_t blocks)
-{
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(gs_msb_phase_buf), (size_t)blocks * 32 * sizeof(uint32_t));
-}
-#endif
 
 size_t gs_msb_temp_bytes(uint64_t num_items, int has_values)
 {

@@ -155,3 +155,17 @@ def test_large_properties(gs, cuda, dist):
     assert inv == 0 and (s1, x1) == (s0, x0)
     bad, vsum = gs.check_pairs_enumerated(orig, seq.sorted_keys, seq.sorted_values)
     assert bad == 0 and vsum == n * (n - 1) // 2
+
+
+@pytest.mark.parametrize("n", [1500, 4000, 9000, 17000, 17408, 40000, 700001])
+def test_all_ones_keys_next_to_padding(gs, cuda, oracle, n):
+    """Keys whose low bits are all ones tie with the local sort's padding value in every digit:
+    none may be displaced by a pad (regression: shared first-pass histogram), for any range size."""
+    keys = oracle.gen_uniform(n, seed=n)
+    keys[::3] |= np.uint32(0x0000FFFF)
+    keys[1::7] = np.uint32(0xFFFFFFFF)
+    keys[5::11] |= np.uint32(0x00FFFFFF)
+    assert np.array_equal(_msb_keys(gs, keys, cuda), np.sort(keys))
+    vals = oracle.gen_enumerated(n)
+    ks, vs = _msb_pairs(gs, keys, vals, cuda)
+    assert oracle.msb_check_pairs_enumerated(keys, ks, vs) == 0
