@@ -12,10 +12,14 @@ constexpr int LSB_WAVES = LSB_THREADS / WAVE;
 constexpr int LSB_KPT = 16;                          // keys per thread per tile
 constexpr int LSB_TILE = LSB_THREADS * LSB_KPT;      // 8192 keys = 32 KiB
 constexpr int LSB_CHUNK = LSB_WAVES;                 // tiles per chunk = waves per upsweep block
-constexpr int LSB_BLOCKS_PER_CU = 2;                 // <=128 VGPRs -> 4 waves/SIMD -> 2 blocks of 8 waves
 constexpr int MI355X_CUS = 256;
 constexpr int MI355X_XCDS = 8;
-constexpr uint32_t LSB_RESIDENT = MI355X_CUS * LSB_BLOCKS_PER_CU;   // downsweep blocks in flight
+// Tiles are handed out in groups of LSB_GROUP consecutive tiles; inside a group the blocks of one
+// XCD take a contiguous slice (tile_of_item), so neighbouring digit runs meet in the same L2.
+#ifndef LSB_GROUP
+#define LSB_GROUP 512
+#endif
+constexpr uint32_t LSB_RESIDENT = LSB_GROUP;
 
 struct PassParams {
     uint32_t n;          // number of keys
