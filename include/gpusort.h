@@ -150,12 +150,13 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes,
 /* 2^bits-bin histogram (u64 counts) of the top `bits` bits of each key. */
 int gs_shard_histogram_u32(const uint32_t *d_keys, uint64_t num_items, int bits,
                            uint64_t *d_hist, int key_type, void *stream);
-/* Partition by destination rank (order inside a rank's group is not defined):
+/* Partition by destination rank:
  * d_dest_of_bin[top `bits` bits] gives the rank (monotone non-decreasing,
  * < num_ranks <= 256).  Writes keys (and values) grouped by rank into d_*_out
- * and the per-rank counts into d_counts[num_ranks] (u64).  d_bin_hist: the
- * histogram gs_shard_histogram_u32 produced for these keys (saves a pass over
- * the keys), or NULL.  d_temp sized by gs_msb_temp_bytes.                    */
+ * and the per-rank counts into d_counts[num_ranks] (u64).  The order inside a
+ * rank's group is the input order (deterministic).  d_bin_hist: accepted for
+ * compatibility and ignored (the partition counts per tile itself), may be
+ * NULL.  d_temp sized by gs_msb_temp_bytes.                                   */
 int gs_shard_partition_u32(void *d_temp, size_t temp_bytes,
                            const uint32_t *d_keys_in, uint32_t *d_keys_out,
                            const uint32_t *d_vals_in, uint32_t *d_vals_out,
