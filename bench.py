@@ -4,7 +4,8 @@
 Contract (one JSON line on rank 0):
   python bench.py --gpus N --steps K --warmup W
   N = 1 : BASELINE.json configs[1] -- LSB radix sort, 2^30 uniform-random u32 keys, keys-only.
-  N > 1 : configs[4] shape -- MSB bucket-sharded sort, 2^30 keys per GPU, one RCCL all-to-all
+  N > 1 : configs[4] shape -- MSB bucket-sharded sort, 2^30 keys per GPU: first digit pass, ONE RCCL
+          all-to-all of the top-level buckets, rest of the MSB sort on the receiver
           (launched by torch.distributed.run, one rank per GPU).
 A "step" is one complete sort of one batch of synthetic keys already resident in HBM.  Every
 step sorts its own pre-generated input buffer (seed = step index), so no restore copy sits in
@@ -98,7 +99,7 @@ def main():
     import gpu_sort_amd as gs
 
     n = 1 << args.log2n
-    algo = args.algo or ("lsb" if world == 1 else "msb")
+    algo = args.algo or ("lsb" if world == 1 and not args.force_sharded else "msb")
     steps, warmup = args.steps, args.warmup
     total = steps + warmup
 
@@ -114,7 +115,9 @@ def main():
     sharded_path = world > 1 or args.force_sharded
     if sharded_path:
         from gpu_sort_amd import sharded
-        runner = sharded.ShardedSorter(n, args.pairs, dev, local_algo=args.algo or "lsb")
+        # default: exchange after the first MSB digit pass; --algo lsb|msb: group-by-destination + full local sort
+        runner = sharded.ShardedSorter(n, args.pairs, dev, local_algo=args.algo or "lsb",
+                                       pipeline="partition" if args.algo else "msb")
         nbytes = 0
         temp = None
     elif algo == "lsb":
@@ -221,7 +224,8 @@ def main():
             "config": {"workload": (f"{algo}_radix_sort_2^{args.log2n}_u32_{args.dist}_"
                                     f"{'pairs' if args.pairs else 'keys_only'}" + ("_per_gpu_sharded" if sharded_path else "")),
                        "keys_per_gpu": n, "has_values": args.pairs,
-                       "algorithm": (f"msb_bucket_shard+local_{args.algo or 'lsb'}" if sharded_path else algo),
+                       "algorithm": ((f"shard_partition+local_{args.algo}" if args.algo else "msb_first_pass+all_to_all+msb_finish")
+                                     if sharded_path else algo),
                        "distribution": args.dist, "parallelism": "single" if not sharded_path else f"msb_bucket_shard{world}"},
             "roofline": roofline, "whole_sort": whole, "cpu_baseline": cpu,
             "kernels_ms_total": {k: [round(v[0], 3), v[1]] for k, v in kernels.items()},

@@ -34,6 +34,9 @@ SIGNATURES = {
     "gs_lsb_downsweep_u32": (i32, [vp, sz, vp, vp, vp, vp, u64, i32, i32, i32, i32, i32, vp]),
     "gs_msb_temp_bytes": (sz, [u64, i32]),
     "gs_msb_sort_u32": (i32, [vp, sz, vp, vp, u64, vp, vp, pp, pp, i32, vp, i32]),
+    "gs_msb_first_pass_u32": (i32, [vp, sz, vp, vp, vp, vp, u64, i32, vp, vp]),
+    "gs_msb_finish_temp_bytes": (sz, [u64, i32, i32]),
+    "gs_msb_finish_u32": (i32, [vp, sz, vp, vp, vp, vp, u64, vp, i32, i32, vp, i32]),
     "gs_shard_histogram_u32": (i32, [vp, u64, i32, vp, i32, vp]),
     "gs_shard_partition_u32": (i32, [vp, sz, vp, vp, vp, vp, u64, i32, vp, i32, vp, vp, i32, vp]),
     "gs_generate_u32": (i32, [vp, u64, i32, u64, u64, i32, vp]),

@@ -49,7 +49,8 @@ __host__ __device__ constexpr uint32_t msb_class_cap(int c) { return (uint32_t)(
 // pairs keep {key,value} in LDS, so their largest class is 9216 (144 KiB would not leave room for two blocks)
 __host__ __device__ constexpr int msb_num_classes(bool has_values) { return has_values ? 3 : 4; }
 
-struct MsbBucket { uint32_t offset, size, tile_start, pad; };   // a bucket still to be partitioned
+struct MsbBucket { uint32_t offset, size, tile_start, tiles; }; // a bucket still to be partitioned (output offset, keys, its tiles)
+struct MsbPiece { uint32_t lo, size, tile_start, bucket; };     // multi-GPU: a bucket arrives in one piece per source rank
 struct MsbTile { uint32_t lo, valid, bucket, pad; };            // one tile of a level: keys [lo, lo + valid)
 struct MsbTask { uint32_t offset, size, sort_bits, pad; };      // a range to finish with a local sort
 struct MsbLevel {
@@ -72,39 +73,43 @@ struct MsbWs {
     uint32_t *spine;                     // [256][stride]
     uint16_t *prefix16;                  // [max_tiles][256]
     MsbTask *tasks[MSB_NCLASS];
+    MsbPiece *pieces;                    // [extra_pieces] (gs_msb_finish_u32 only)
     uint32_t max_buckets, max_tasks, max_tiles, stride;
 };
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-static inline uint32_t msb_max_buckets(uint64_t n, bool has_values)
+// `extra`: pieces of the multi-GPU finish (each may add a ragged tile), 0 otherwise
+static inline uint32_t msb_max_buckets(uint64_t n, bool has_values, uint32_t extra = 0)
 {
-    return (uint32_t)(n / msb_class_cap(msb_num_classes(has_values) - 1)) + RADIX + 1;
+    return (uint32_t)(n / msb_class_cap(msb_num_classes(has_values) - 1)) + RADIX + 1 + extra;
 }
-static inline uint32_t msb_max_tasks(uint64_t n, bool has_values)
+static inline uint32_t msb_max_tasks(uint64_t n, bool has_values, uint32_t extra = 0)
 {
     // a task is either >= MSB_MERGE keys or is followed by something that did not fit: <= 2n/MERGE,
     // plus up to 256 per partitioned bucket
-    return (uint32_t)(2 * n / MSB_MERGE) + msb_max_buckets(n, has_values) + 2 * RADIX;
+    return (uint32_t)(2 * n / MSB_MERGE) + msb_max_buckets(n, has_values, extra) + 2 * RADIX;
 }
 // tiles of a level: n / TILE full ones + one ragged tile per bucket, padded to whole chunks + one spare chunk
-static inline uint32_t msb_max_tiles(uint64_t n, bool has_values)
+static inline uint32_t msb_max_tiles(uint64_t n, bool has_values, uint32_t extra = 0)
 {
-    const uint64_t t = n / MSB_TILE + msb_max_buckets(n, has_values) + 1;
+    const uint64_t t = n / MSB_TILE + msb_max_buckets(n, has_values, extra) + 1;
     return (uint32_t)((t / MSB_WAVES + 2) * MSB_WAVES);
 }
-static size_t msb_ws_bytes(uint64_t n, bool has_values)
+static size_t msb_ws_bytes(uint64_t n, bool has_values, uint32_t extra = 0)
 {
-    const size_t mb = msb_max_buckets(n, has_values), mt = msb_max_tasks(n, has_values), ml = msb_max_tiles(n, has_values);
+    const size_t mb = msb_max_buckets(n, has_values, extra), mt = msb_max_tasks(n, has_values, extra),
+                 ml = msb_max_tiles(n, has_values, extra);
     return align256(5 * sizeof(MsbLevel)) + 2 * align256(mb * sizeof(MsbBucket)) + align256(ml * sizeof(MsbTile)) +
            align256(mb * RADIX * sizeof(uint32_t)) + align256((size_t)RADIX * (ml / MSB_WAVES) * sizeof(uint32_t)) +
-           align256(ml * RADIX * sizeof(uint16_t)) + MSB_NCLASS * align256(mt * sizeof(MsbTask));
+           align256(ml * RADIX * sizeof(uint16_t)) + MSB_NCLASS * align256(mt * sizeof(MsbTask)) +
+           align256((size_t)extra * sizeof(MsbPiece));
 }
-static MsbWs msb_carve(void *temp, uint64_t n, bool has_values)
+static MsbWs msb_carve(void *temp, uint64_t n, bool has_values, uint32_t extra = 0)
 {
     MsbWs ws;
-    ws.max_buckets = msb_max_buckets(n, has_values);
-    ws.max_tasks = msb_max_tasks(n, has_values);
-    ws.max_tiles = msb_max_tiles(n, has_values);
+    ws.max_buckets = msb_max_buckets(n, has_values, extra);
+    ws.max_tasks = msb_max_tasks(n, has_values, extra);
+    ws.max_tiles = msb_max_tiles(n, has_values, extra);
     ws.stride = ws.max_tiles / MSB_WAVES;
     char *c = (char *)temp;
     ws.level = (MsbLevel *)c; c += align256(5 * sizeof(MsbLevel));
@@ -114,6 +119,7 @@ static MsbWs msb_carve(void *temp, uint64_t n, bool has_values)
     ws.spine = (uint32_t *)c; c += align256((size_t)RADIX * ws.stride * sizeof(uint32_t));
     ws.prefix16 = (uint16_t *)c; c += align256((size_t)ws.max_tiles * RADIX * sizeof(uint16_t));
     for (int i = 0; i < MSB_NCLASS; ++i) { ws.tasks[i] = (MsbTask *)c; c += align256((size_t)ws.max_tasks * sizeof(MsbTask)); }
+    ws.pieces = (MsbPiece *)c;
     return ws;
 }
 
@@ -126,7 +132,7 @@ __global__ void msb_init_kernel(MsbWs ws, uint32_t n)
         if (t == 0) z.packed = (1ull << 32) | ((n + MSB_TILE - 1) / MSB_TILE);
         ws.level[t] = z;
     }
-    if (t == 0) ws.buckets[0][0] = MsbBucket{0u, n, 0u, 0u};
+    if (t == 0) ws.buckets[0][0] = MsbBucket{0u, n, 0u, (n + MSB_TILE - 1) / MSB_TILE};
 }
 
 // direct path for arrays that fit one workgroup: a single task on all 32 bits
@@ -144,10 +150,23 @@ __global__ __launch_bounds__(256) void msb_expand_kernel(MsbWs ws, int L)
     const uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const MsbBucket B = ws.buckets[L & 1][b];
-        const uint32_t tiles = (B.size + MSB_TILE - 1) / MSB_TILE;
-        for (uint32_t t = threadIdx.x; t < tiles; t += blockDim.x) {
+        for (uint32_t t = threadIdx.x; t < B.tiles; t += blockDim.x) {
             const uint32_t lo = B.offset + t * MSB_TILE, left = B.size - t * MSB_TILE;
             ws.tiles[B.tile_start + t] = MsbTile{lo, left < (uint32_t)MSB_TILE ? left : (uint32_t)MSB_TILE, b, 0u};
+        }
+    }
+}
+
+// multi-GPU finish: the level's buckets arrive in pieces (one per source rank) that lie anywhere in
+// the source buffer; a bucket's pieces own consecutive tile ranges
+__global__ __launch_bounds__(256) void msb_expand_pieces_kernel(MsbWs ws, uint32_t npieces)
+{
+    for (uint32_t q = blockIdx.x; q < npieces; q += gridDim.x) {
+        const MsbPiece P = ws.pieces[q];
+        const uint32_t tiles = (P.size + MSB_TILE - 1) / MSB_TILE;
+        for (uint32_t t = threadIdx.x; t < tiles; t += blockDim.x) {
+            const uint32_t left = P.size - t * MSB_TILE;
+            ws.tiles[P.tile_start + t] = MsbTile{P.lo + t * MSB_TILE, left < (uint32_t)MSB_TILE ? left : (uint32_t)MSB_TILE, P.bucket, 0u};
         }
     }
 }
@@ -283,7 +302,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
         if (counts0) {
             c = counts0[d];
         } else {
-            const uint32_t g0 = B.tile_start, g1 = g0 + (B.size + MSB_TILE - 1) / MSB_TILE;
+            const uint32_t g0 = B.tile_start, g1 = g0 + B.tiles;
             const uint32_t *srow = ws.spine + (size_t)d * ws.stride;
             e0 = srow[g0 / MSB_WAVES] + ws.prefix16[(size_t)g0 * RADIX + d];
             c = srow[g1 / MSB_WAVES] + ws.prefix16[(size_t)g1 * RADIX + d] - e0;
@@ -342,7 +361,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
         __syncthreads();
         if (is_large) {
             new_bucket = (uint32_t)(s_base64 >> 32) + bidx;
-            ws.buckets[(L + 1) & 1][new_bucket] = MsbBucket{abs, c, (uint32_t)s_base64 + tidx, 0u};
+            ws.buckets[(L + 1) & 1][new_bucket] = MsbBucket{abs, c, (uint32_t)s_base64 + tidx, tiles};
         } else if (tsize) {
             ws.tasks[cls][s_cbase[cls] + task_local] = MsbTask{abs, tsize, rb + (s_nsub[d] > 1 ? 8u : 0u), 0u};
         }
@@ -538,7 +557,7 @@ __device__ __forceinline__ void msb_scatter_tile(ScatterSmem<HAS_VALUES, REMAP> 
 template <bool HAS_VALUES, bool REMAP, bool TWOUT, bool FULL, bool BIG>
 __global__ __launch_bounds__(MSB_THREADS, HAS_VALUES ? 4 : 6) void msb_scatter_kernel(
     MsbWs ws, int L, const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k, const uint32_t *__restrict__ src_v,
-    uint32_t *__restrict__ dst_v, DigitSel ds, int f32_out, uint32_t xor_out)
+    uint32_t *__restrict__ dst_v, DigitSel ds, int f32_out, uint32_t xor_out, int ragged_anywhere)
 {
     __shared__ __attribute__((aligned(16))) ScatterSmem<HAS_VALUES, REMAP> sm;
     const unsigned long long packed = ws.level[L].packed;
@@ -546,6 +565,9 @@ __global__ __launch_bounds__(MSB_THREADS, HAS_VALUES ? 4 : 6) void msb_scatter_k
     if (FULL) {
         if (blockIdx.x >= (uint32_t)packed) return;
         g = tile_of_item(blockIdx.x, (uint32_t)packed);   // neighbouring tiles on one XCD: their runs meet in one L2
+    } else if (ragged_anywhere) {                         // buckets in pieces: one block per tile, full ones skipped
+        if (blockIdx.x >= (uint32_t)packed) return;
+        g = blockIdx.x;
     } else {
         if (blockIdx.x >= (uint32_t)(packed >> 32)) return;
         const MsbBucket B = ws.buckets[L & 1][blockIdx.x];
@@ -553,7 +575,7 @@ __global__ __launch_bounds__(MSB_THREADS, HAS_VALUES ? 4 : 6) void msb_scatter_k
         g = B.tile_start + B.size / (uint32_t)MSB_TILE;
     }
     const MsbTile T = ws.tiles[g];
-    if (FULL && T.valid != (uint32_t)MSB_TILE) return;
+    if (FULL ? T.valid != (uint32_t)MSB_TILE : T.valid == (uint32_t)MSB_TILE) return;
     if (REMAP) load_remap(ds, sm.tab);
     msb_scatter_tile<HAS_VALUES, REMAP, TWOUT, FULL, BIG>(sm, ds, ws.cursors + (size_t)T.bucket * RADIX, ws.spine + g / MSB_WAVES,
                                                           ws.stride, ws.prefix16 + (size_t)g * RADIX, src_k, dst_k, src_v, dst_v,
@@ -562,19 +584,22 @@ __global__ __launch_bounds__(MSB_THREADS, HAS_VALUES ? 4 : 6) void msb_scatter_k
 
 template <bool HAS_VALUES, bool REMAP, bool TWOUT>
 static void launch_scatter(const MsbWs &ws, int L, uint32_t tiles_ub, uint32_t buckets_ub, bool big, const uint32_t *sk, uint32_t *dk,
-                           const uint32_t *sv, uint32_t *dv, const DigitSel &ds, int f32_out, uint32_t xor_out, hipStream_t s)
+                           const uint32_t *sv, uint32_t *dv, const DigitSel &ds, int f32_out, uint32_t xor_out, hipStream_t s,
+                           bool ragged_anywhere = false)
 {
     const dim3 blk(MSB_THREADS);
+    const dim3 rg(ragged_anywhere ? tiles_ub : buckets_ub);
+    const int ra = ragged_anywhere ? 1 : 0;
     if (big) {
         hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, REMAP, TWOUT, true, true>), dim3(tiles_ub), blk, 0, s, ws, L, sk, dk, sv, dv,
-                           ds, f32_out, xor_out);
-        hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, REMAP, TWOUT, false, true>), dim3(buckets_ub), blk, 0, s, ws, L, sk, dk, sv,
-                           dv, ds, f32_out, xor_out);
+                           ds, f32_out, xor_out, 0);
+        hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, REMAP, TWOUT, false, true>), rg, blk, 0, s, ws, L, sk, dk, sv, dv, ds,
+                           f32_out, xor_out, ra);
     } else {
         hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, REMAP, TWOUT, true, false>), dim3(tiles_ub), blk, 0, s, ws, L, sk, dk, sv, dv,
-                           ds, f32_out, xor_out);
-        hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, REMAP, TWOUT, false, false>), dim3(buckets_ub), blk, 0, s, ws, L, sk, dk, sv,
-                           dv, ds, f32_out, xor_out);
+                           ds, f32_out, xor_out, 0);
+        hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, REMAP, TWOUT, false, false>), rg, blk, 0, s, ws, L, sk, dk, sv, dv, ds,
+                           f32_out, xor_out, ra);
     }
 }
 
@@ -906,6 +931,60 @@ static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uin
 #undef GS_LS
 }
 
+// Levels 1..3 (partition on bytes 2, 1, 0 + the local sorts after each): keys travel between
+// buf[1] (level-1 source) and buf[0] (level-1 destination and final result).  `npieces` != 0:
+// the level-1 buckets and their pieces were written by the host (gs_msb_finish_u32) and the tile
+// records come from the pieces.
+static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint32_t npieces, uint32_t *const buf_k[2],
+                           uint32_t *const buf_v[2], const PassParams &tw, hipStream_t s)
+{
+    const int nclass = msb_num_classes(pairs);
+    const uint32_t tiles_all = (uint32_t)((num_items + MSB_TILE - 1) / MSB_TILE);
+    const uint32_t max_tasks_lvl = ws.max_tasks;
+    uint32_t *d_keys = buf_k[0], *d_vals = buf_v[0];
+    for (int L = 1; L <= 3; ++L) {
+        const int shift = 24 - 8 * L;
+        const DigitSel dsel{shift, nullptr, 0, 0, 0u};
+        uint32_t *sk = buf_k[L & 1], *dk = buf_k[(L + 1) & 1];
+        uint32_t *sv = buf_v[L & 1], *dv = buf_v[(L + 1) & 1];
+        const bool in_pieces = npieces != 0 && L == 1;
+        // buckets at level L: <= 256 at level 1, else bounded by size; tiles: n/T + one ragged tile per bucket (piece)
+        const uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
+        const uint32_t max_tiles = tiles_all + (in_pieces ? npieces : max_b);
+        // one tile per block, dispatched in order (blocks that own a long run of tiles march in
+        // lockstep and lose a third of the bandwidth, like the LSB downsweep); surplus blocks exit
+        const bool last = (L == 3);
+        { KernelTimer kt(GS_K_MSB_HISTOGRAM, s);
+          if (in_pieces) {
+              hipLaunchKernelGGL(msb_expand_pieces_kernel, dim3(npieces < 4096u ? npieces : 4096u), dim3(256), 0, s, ws, npieces);
+          } else {
+              const uint32_t eg = max_b < 4096u ? max_b : 4096u;
+              hipLaunchKernelGGL(msb_expand_kernel, dim3(eg), dim3(256), 0, s, ws, L);
+          }
+          const uint32_t hg_ub = max_tiles / MSB_WAVES + 1;                 // one block per chunk
+          const uint32_t hg = hg_ub < MSB_MAX_GRID ? hg_ub : MSB_MAX_GRID;
+          hipLaunchKernelGGL(msb_upsweep_kernel<false>, dim3(hg), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, dsel);
+          hipLaunchKernelGGL(msb_scan_kernel, dim3(RADIX), dim3(1024), 0, s, ws, L); }
+        { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
+          const uint32_t cg = max_b < 4096u ? max_b : 4096u;
+          if (last) hipLaunchKernelGGL(msb_classify_kernel<true>, dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass);
+          else hipLaunchKernelGGL(msb_classify_kernel<false>, dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass); }
+        { KernelTimer kt(GS_K_MSB_PARTITION, s);
+          const bool big = num_items > (1ull << 30);
+          const uint32_t *svc = pairs ? (const uint32_t *)sv : (const uint32_t *)nullptr;
+          uint32_t *dvc = pairs ? dv : (uint32_t *)nullptr;
+#define GS_SC(HV, TW) launch_scatter<HV, false, TW>(ws, L, max_tiles, max_b, big, (const uint32_t *)sk, dk, svc, dvc, dsel, tw.f32_out, tw.xor_out, s, in_pieces)
+          if (pairs) { if (last) GS_SC(true, true); else GS_SC(true, false); }
+          else { if (last) GS_SC(false, true); else GS_SC(false, false); }
+#undef GS_SC
+        }
+        if (!last) {
+            if (pairs) launch_local_sorts<true>(ws, L, max_tasks_lvl, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s);
+            else launch_local_sorts<false>(ws, L, max_tasks_lvl, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s);
+        }
+    }
+}
+
 }  // namespace gs
 
 using namespace gs;
@@ -950,7 +1029,6 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
         if (pairs) launch_local_sorts<true>(ws, 0, 1, d_keys, d_keys, d_vals, d_vals, tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out, s);
         else launch_local_sorts<false>(ws, 0, 1, d_keys, d_keys, nullptr, nullptr, tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out, s);
     } else {
-        const uint32_t tiles_all = (n + MSB_TILE - 1) / MSB_TILE;
         uint32_t *buf_k[2] = {d_keys, d_keys_alt};
         uint32_t *buf_v[2] = {d_vals, d_vals_alt};
         // level 0: the top byte with one stable LSB pass, IN -> ALT (keys stay twiddled)
@@ -968,46 +1046,106 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
         if (pairs) launch_local_sorts<true>(ws, 0, task_grid0, d_keys_alt, d_keys, d_vals_alt, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s);
         else launch_local_sorts<false>(ws, 0, task_grid0, d_keys_alt, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s);
 
-        for (int L = 1; L <= 3; ++L) {
-            const int shift = 24 - 8 * L;
-            const DigitSel dsel{shift, nullptr, 0, 0, 0u};
-            uint32_t *sk = buf_k[L & 1], *dk = buf_k[(L + 1) & 1];
-            uint32_t *sv = buf_v[L & 1], *dv = buf_v[(L + 1) & 1];
-            // buckets at level L: <= 256 at level 1, else bounded by size; tiles: n/T + one ragged tile per bucket
-            const uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
-            const uint32_t max_tiles_ub = tiles_all + max_b;
-            // one tile per block, dispatched in order (blocks that own a long run of tiles march in
-            // lockstep and lose a third of the bandwidth, like the LSB downsweep); surplus blocks exit
-            static const char *capenv = getenv("GS_MSB_GRID_CAP");   // experiments
-            const uint32_t cap = capenv ? (uint32_t)atoi(capenv) : 0xffffffffu;
-            const uint32_t max_tiles = max_tiles_ub < cap ? max_tiles_ub : cap;
-            const bool last = (L == 3);
-            { KernelTimer kt(GS_K_MSB_HISTOGRAM, s);
-              const uint32_t eg = max_b < 4096u ? max_b : 4096u;
-              hipLaunchKernelGGL(msb_expand_kernel, dim3(eg), dim3(256), 0, s, ws, L);
-              const uint32_t hg_ub = max_tiles_ub / MSB_WAVES + 1;                 // one block per chunk
-              const uint32_t hg = hg_ub < MSB_MAX_GRID ? hg_ub : MSB_MAX_GRID;
-              hipLaunchKernelGGL(msb_upsweep_kernel<false>, dim3(hg), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, dsel);
-              hipLaunchKernelGGL(msb_scan_kernel, dim3(RADIX), dim3(1024), 0, s, ws, L); }
-            { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
-              const uint32_t cg = max_b < 4096u ? max_b : 4096u;
-              if (last) hipLaunchKernelGGL(msb_classify_kernel<true>, dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass);
-              else hipLaunchKernelGGL(msb_classify_kernel<false>, dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass); }
-            { KernelTimer kt(GS_K_MSB_PARTITION, s);
-              const bool big = num_items > (1ull << 30);
-              const uint32_t *svc = pairs ? (const uint32_t *)sv : (const uint32_t *)nullptr;
-              uint32_t *dvc = pairs ? dv : (uint32_t *)nullptr;
-#define GS_SC(HV, TW) launch_scatter<HV, false, TW>(ws, L, max_tiles, max_b, big, (const uint32_t *)sk, dk, svc, dvc, dsel, tw.f32_out, tw.xor_out, s)
-              if (pairs) { if (last) GS_SC(true, true); else GS_SC(true, false); }
-              else { if (last) GS_SC(false, true); else GS_SC(false, false); }
-#undef GS_SC
-            }
-            if (!last) {
-                if (pairs) launch_local_sorts<true>(ws, L, max_tasks_lvl, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s);
-                else launch_local_sorts<false>(ws, L, max_tasks_lvl, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s);
-            }
-        }
+        msb_run_levels(ws, num_items, pairs, /*pieces=*/0u, buf_k, buf_v, tw, s);
     }
+    int err = (int)hipGetLastError();
+    if (err) return err;
+    if (synchronize) err = (int)hipStreamSynchronize(s);
+    return err;
+}
+
+// ---- the MSB path cut at the exchange point of the multi-GPU sort (north_star:
+// "a single RCCL all-to-all after the first digit pass")
+
+__global__ void msb_counts64_kernel(const uint32_t *__restrict__ totals, unsigned long long *__restrict__ out)
+{
+    out[threadIdx.x] = totals[threadIdx.x];
+}
+
+int gs_msb_first_pass_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys_in, uint32_t *d_keys_out,
+                          const uint32_t *d_vals_in, uint32_t *d_vals_out, uint64_t num_items, int key_type,
+                          uint64_t *d_bucket_counts, void *stream)
+{
+    if (num_items >= (1ull << 32) || !d_bucket_counts) return hipErrorInvalidValue;
+    if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    if (num_items == 0) return (int)hipMemsetAsync(d_bucket_counts, 0, RADIX * sizeof(uint64_t), s);
+    if ((d_vals_in == nullptr) != (d_vals_out == nullptr) || !d_keys_in || !d_keys_out) return hipErrorInvalidValue;
+    if (!d_temp || temp_bytes < lsb_temp_bytes(num_items)) return hipErrorInvalidValue;
+    const LsbWorkspace lw = lsb_carve(d_temp, num_items);
+    PassParams p0 = lsb_make_params(num_items, 24, 8);
+    lsb_twiddle_masks(key_type, 0, true, false, p0);          // keys leave in their order-preserving u32 form
+    int e;
+    if ((e = lsb_upsweep(d_keys_in, lw.spine, lw.prefix16, p0, s))) return e;
+    if ((e = lsb_scan(lw.spine, lw.totals, p0.grid, s))) return e;
+    if ((e = lsb_downsweep(d_keys_in, d_keys_out, d_vals_in, d_vals_out, lw.spine, lw.prefix16, lw.totals, p0, s))) return e;
+    hipLaunchKernelGGL(msb_counts64_kernel, dim3(1), dim3(RADIX), 0, s, (const uint32_t *)lw.totals,
+                       (unsigned long long *)d_bucket_counts);
+    return (int)hipGetLastError();
+}
+
+size_t gs_msb_finish_temp_bytes(uint64_t num_items, int has_values, int num_src)
+{
+    const uint32_t extra = (uint32_t)(num_src > 0 ? num_src : 0) * RADIX;
+    return align256(lsb_temp_bytes(num_items)) + msb_ws_bytes(num_items, has_values != 0, extra);
+}
+
+int gs_msb_finish_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t *d_vals, uint32_t *d_keys_out,
+                      uint32_t *d_vals_out, uint64_t num_items, const uint64_t *h_piece_counts, int num_src, int key_type,
+                      void *stream, int synchronize)
+{
+    if (num_items >= (1ull << 32) || num_src < 1 || num_src > RADIX || !h_piece_counts) return hipErrorInvalidValue;
+    if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;
+    // bucket b = all pieces (s, b); the buffer holds source 0's pieces in byte order, then source 1's, ...
+    uint64_t total = 0;
+    for (int i = 0; i < num_src * RADIX; ++i) total += h_piece_counts[i];
+    if (total != num_items) return hipErrorInvalidValue;
+    if (num_items == 0) return hipSuccess;
+    const bool pairs = d_vals != nullptr;
+    if (!d_keys || !d_keys_out || (pairs && !d_vals_out)) return hipErrorInvalidValue;
+    if (!d_temp || temp_bytes < gs_msb_finish_temp_bytes(num_items, pairs, num_src)) return hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t extra = (uint32_t)num_src * RADIX;
+    const MsbWs ws = msb_carve((char *)d_temp + align256(lsb_temp_bytes(num_items)), num_items, pairs, extra);
+
+    // host side of what the level-0 classification does on one GPU: bucket list + pieces of level 1
+    MsbBucket hb[RADIX];
+    MsbPiece *hp = new MsbPiece[(size_t)num_src * RADIX];
+    uint64_t *src_off = new uint64_t[(size_t)num_src * RADIX];
+    uint64_t run = 0;
+    for (int sidx = 0; sidx < num_src; ++sidx)
+        for (int b = 0; b < RADIX; ++b) { src_off[sidx * RADIX + b] = run; run += h_piece_counts[sidx * RADIX + b]; }
+    uint32_t nb = 0, np = 0, tile = 0;
+    uint64_t out_off = 0;
+    for (int b = 0; b < RADIX; ++b) {
+        uint64_t size = 0;
+        for (int sidx = 0; sidx < num_src; ++sidx) size += h_piece_counts[sidx * RADIX + b];
+        if (size == 0) continue;
+        const uint32_t tile_start = tile;
+        for (int sidx = 0; sidx < num_src; ++sidx) {
+            const uint64_t c = h_piece_counts[sidx * RADIX + b];
+            if (c == 0) continue;
+            hp[np++] = MsbPiece{(uint32_t)src_off[sidx * RADIX + b], (uint32_t)c, tile, nb};
+            tile += (uint32_t)((c + MSB_TILE - 1) / MSB_TILE);
+        }
+        hb[nb++] = MsbBucket{(uint32_t)out_off, (uint32_t)size, tile_start, tile - tile_start};
+        out_off += size;
+    }
+    MsbLevel hl[5] = {};
+    hl[1].packed = ((unsigned long long)nb << 32) | tile;
+    hipError_t e = hipMemcpyAsync(ws.level, hl, sizeof(hl), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(ws.buckets[1], hb, nb * sizeof(MsbBucket), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(ws.pieces, hp, np * sizeof(MsbPiece), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);            // the host tables go out of scope below
+    delete[] hp;
+    delete[] src_off;
+    if (e != hipSuccess) return (int)e;
+
+    PassParams tw{};
+    lsb_twiddle_masks(key_type, 0, true, true, tw);
+    uint32_t *buf_k[2] = {d_keys_out, d_keys};                  // level 1 reads the received buffer, writes the output
+    uint32_t *buf_v[2] = {d_vals_out, d_vals};
+    msb_run_levels(ws, num_items, pairs, np, buf_k, buf_v, tw, s);
     int err = (int)hipGetLastError();
     if (err) return err;
     if (synchronize) err = (int)hipStreamSynchronize(s);

@@ -1,13 +1,21 @@
 """Multi-GPU bucket-sharded sort: one process per GPU, ONE all-to-all (RCCL over xGMI).
 
-The reference is single-GPU; this is the north_star's 8-GPU path:
-  1. every rank histograms the top SHARD_BITS bits of its shard        (gs_shard_histogram_u32)
-  2. all ranks exchange the histograms (all_gather, 32 KiB)            (torch.distributed)
-  3. every rank computes the same monotone bin -> rank map with balanced totals
-  4. every rank groups its keys (and values) by destination rank        (gs_shard_partition_u32)
-  5. one all_to_all_single with uneven splits moves every key to its owner
-  6. every rank sorts what it received                                  (gs_lsb_sort_u32 / gs_msb_sort_u32)
+The reference is single-GPU; this is the north_star's 8-GPU path, the MSB sort
+cut at its first digit ("msb" pipeline, the default):
+  1. every rank runs the MSB path's first digit pass on its shard: keys grouped by top byte
+     + the 256 bucket sizes                                             (gs_msb_first_pass_u32)
+  2. all ranks exchange the bucket sizes (all_gather, 2 KiB)            (torch.distributed)
+  3. every rank computes the same monotone bucket -> rank map with balanced totals; a rank's
+     share is then ONE contiguous slice of every grouped shard
+  4. one all_to_all_single with uneven splits moves every top-level bucket to its owner
+  5. every rank finishes the MSB sort on the buckets it received, picking the pieces up where
+     they lie (no regrouping pass)                                      (gs_msb_finish_u32)
 Rank r then holds the r-th slice of the globally sorted sequence.
+
+When 256 buckets cannot balance the ranks (a heavy top byte), the "partition" pipeline is used
+instead (decided identically on every rank from the gathered sizes): 4096-bin histogram of the
+top SHARD_BITS bits (gs_shard_histogram_u32), group-by-destination (gs_shard_partition_u32), the
+same single all-to-all, then a full local sort (gs_lsb_sort_u32 / gs_msb_sort_u32).
 
 The compute steps go through `ops` (DeviceOps = the HIP library).  The host logic --
 split computation and exchange plan -- is backend-independent, so the CPU test-suite
@@ -73,8 +81,29 @@ class DeviceOps:
                                                    self._sp(None)), "gs_shard_partition_u32")
         return counts
 
-    def temp_bytes(self, n, pairs):
-        return max(self.lib.gs_msb_temp_bytes(n, int(pairs)), self.lib.gs_lsb_temp_bytes(n, int(pairs)), 256)
+    def temp_bytes(self, n, pairs, world=1):
+        return max(self.lib.gs_msb_temp_bytes(n, int(pairs)), self.lib.gs_lsb_temp_bytes(n, int(pairs)),
+                   self.lib.gs_msb_finish_temp_bytes(n, int(pairs), world), 256)
+
+    def first_pass(self, keys, vals, n, temp, keys_out, vals_out):
+        """MSB level 0 on its own: grouped keys (values) + the 256 bucket sizes (int64, on the device)."""
+        counts = torch.empty(256, dtype=torch.int64, device=self.device)
+        self.check(self.lib.gs_msb_first_pass_u32(temp.data_ptr(), temp.numel(), keys.data_ptr(), keys_out.data_ptr(),
+                                                  vals.data_ptr() if vals is not None else None,
+                                                  vals_out.data_ptr() if vals is not None else None, n,
+                                                  self._lib.GS_KEY_U32, counts.data_ptr(), self._sp(None)),
+                   "gs_msb_first_pass_u32")
+        return counts
+
+    def finish(self, keys, vals, m, keys_out, vals_out, piece_counts, temp):
+        """The rest of the MSB sort on received buckets; piece_counts: (num_src, 256) host array."""
+        pc = np.ascontiguousarray(piece_counts, dtype=np.uint64)
+        self.check(self.lib.gs_msb_finish_u32(temp.data_ptr(), temp.numel(), keys.data_ptr(),
+                                              vals.data_ptr() if vals is not None else None, keys_out.data_ptr(),
+                                              vals_out.data_ptr() if vals is not None else None, m,
+                                              pc.ctypes.data_as(C.c_void_p), pc.shape[0], self._lib.GS_KEY_U32,
+                                              self._sp(None), 0), "gs_msb_finish_u32")
+        return keys_out, vals_out
 
     def local_sort(self, keys, vals, n, keys_alt, vals_alt, temp, algo="lsb"):
         from . import DoubleBuffer, DeviceRadixSort, rdxsrt_unstable_sort, GS_KEY_U32
@@ -102,8 +131,13 @@ class DeviceOps:
 class ShardedSorter:
     """Sorts a key array that is sharded over the ranks of the default process group."""
 
-    def __init__(self, keys_per_rank, pairs, device, ops=None, local_algo="lsb", slack=1.25, group=None):
+    def __init__(self, keys_per_rank, pairs, device, ops=None, local_algo="lsb", slack=1.25, group=None, pipeline="msb",
+                 max_imbalance=1.2):
+        """pipeline: "msb" (exchange after the first digit pass, falls back when 256 buckets leave a rank with
+        more than max_imbalance x its fair share) or "partition" (12-bit group-by-destination + full local sort,
+        local_algo = "lsb" | "msb")."""
         self.n, self.pairs, self.device, self.group = keys_per_rank, pairs, device, group
+        self.pipeline, self.max_imbalance = pipeline, max_imbalance
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.ops = ops if ops is not None else DeviceOps(device)
@@ -121,12 +155,17 @@ class ShardedSorter:
         self.recv_k, self.alt_k = self.ops.empty(cap), self.ops.empty(cap)
         self.recv_v = self.ops.empty(cap) if self.pairs else None
         self.alt_v = self.ops.empty(cap) if self.pairs else None
-        self.temp = torch.empty(self.ops.temp_bytes(max(cap, self.n), self.pairs), dtype=torch.uint8, device=self.device)
+        self.temp = torch.empty(self.ops.temp_bytes(max(cap, self.n), self.pairs, self.world), dtype=torch.uint8,
+                                device=self.device)
 
     def sort(self, keys, vals=None):
         """keys (and vals): this rank's shard (device tensors of self.n elements).
         Returns (sorted_keys, sorted_vals, count): this rank's slice of the global order."""
         n, world, rank = self.n, self.world, self.rank
+        if self.pipeline == "msb":
+            out = self._sort_msb(keys, vals)
+            if out is not None:
+                return out
         hist = self.ops.histogram(keys, n, SHARD_BITS)
         if world > 1:
             gathered = torch.empty(world * hist.numel(), dtype=hist.dtype, device=hist.device)
@@ -151,7 +190,41 @@ class ShardedSorter:
                 raise RuntimeError("internal: single-rank receive exceeds shard size")
         sk, sv = self.ops.local_sort(rk, rv, m, self.alt_k if world > 1 else self.recv_k,
                                      self.alt_v if world > 1 else self.recv_v, self.temp, self.local_algo)
-        self.last = dict(count=m, send=send, recv=recv, per_rank=per_rank, dest=dest)
+        self.last = dict(count=m, send=send, recv=recv, per_rank=per_rank, dest=dest, pipeline="partition")
+        return sk, sv, m
+
+    def _gather_counts(self, counts):
+        if self.world > 1:
+            gathered = torch.empty(self.world * counts.numel(), dtype=counts.dtype, device=counts.device)
+            dist.all_gather_into_tensor(gathered, counts, group=self.group)
+            return gathered.cpu().numpy().reshape(self.world, -1)
+        return counts.cpu().numpy().reshape(1, -1)
+
+    def _sort_msb(self, keys, vals):
+        """Exchange after the first digit pass.  Returns None when top-byte buckets cannot balance the ranks
+        (every rank takes the same decision: it is a function of the gathered sizes only)."""
+        n, world, rank = self.n, self.world, self.rank
+        counts = self.ops.first_pass(keys, vals, n, self.temp, self.part_k, self.part_v)
+        hist_all = self._gather_counts(counts)                       # (world, 256)
+        dest, per_rank = compute_splits(hist_all, world)
+        total = int(hist_all.sum())
+        if world > 1 and total and per_rank.max() > self.max_imbalance * total / world:
+            return None
+        send, recv = exchange_plan(hist_all, dest, rank, world)
+        m = int(recv.sum())
+        if m > self.cap:
+            self._alloc(int(m * 1.1) + 4096)
+        if world > 1:
+            # bucket order = key order and dest is monotone: rank r's share is one contiguous slice of part_k
+            dist.all_to_all_single(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), group=self.group)
+            if self.pairs:
+                dist.all_to_all_single(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), group=self.group)
+            rk, rv = self.recv_k, self.recv_v
+        else:
+            rk, rv = self.part_k, self.part_v
+        pieces = np.where(dest[None, :] == rank, hist_all, 0)       # what every source sent me, per top byte
+        sk, sv = self.ops.finish(rk, rv, m, self.alt_k, self.alt_v, pieces, self.temp)
+        self.last = dict(count=m, send=send, recv=recv, per_rank=per_rank, dest=dest, pipeline="msb")
         return sk, sv, m
 
     def verify(self, sorted_keys, count, input_checksum=None):

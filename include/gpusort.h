@@ -147,6 +147,26 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes,
  * is issued by the host between these calls (no reference
  * counterpart -- the reference is single-GPU).                               */
 
+/* The MSB path cut at the exchange point (north_star: "a single RCCL all-to-all after the
+ * first digit pass"): gs_msb_first_pass_u32 is the top-byte partition on its own -- keys (and
+ * values) leave grouped by top byte in d_*_out, in their order-preserving u32 form, and
+ * d_bucket_counts[256] (u64) gets the bucket sizes; d_temp sized by gs_lsb_temp_bytes.  The
+ * host assigns contiguous bucket ranges to ranks, so every rank's share is one contiguous
+ * slice of d_keys_out and goes out in ONE all-to-all.  gs_msb_finish_u32 completes the sort on
+ * the receiving rank: d_keys holds, source after source, each source's slice (its buckets in
+ * byte order); h_piece_counts[num_src][256] (HOST memory) are the piece sizes.  The buckets are
+ * picked up where they lie -- no regrouping pass -- and the sorted keys (in key_type's own
+ * representation) land in d_keys_out; d_keys / d_vals are clobbered.  d_temp sized by
+ * gs_msb_finish_temp_bytes.                                                            */
+int gs_msb_first_pass_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys_in,
+                          uint32_t *d_keys_out, const uint32_t *d_vals_in, uint32_t *d_vals_out,
+                          uint64_t num_items, int key_type, uint64_t *d_bucket_counts, void *stream);
+size_t gs_msb_finish_temp_bytes(uint64_t num_items, int has_values, int num_src);
+int gs_msb_finish_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t *d_vals,
+                      uint32_t *d_keys_out, uint32_t *d_vals_out, uint64_t num_items,
+                      const uint64_t *h_piece_counts, int num_src, int key_type, void *stream,
+                      int synchronize);
+
 /* 2^bits-bin histogram (u64 counts) of the top `bits` bits of each key. */
 int gs_shard_histogram_u32(const uint32_t *d_keys, uint64_t num_items, int bits,
                            uint64_t *d_hist, int key_type, void *stream);

@@ -43,13 +43,16 @@ def test_histogram_and_partition(gs, cuda, oracle, n, dist_kind):
 
 
 @pytest.mark.parametrize("pairs", [False, True])
-@pytest.mark.parametrize("algo", ["lsb", "msb"])
+@pytest.mark.parametrize("algo", ["lsb", "msb", "pipeline-msb"])
 def test_sharded_sorter_single_rank(gs, cuda, oracle, pairs, algo):
     from gpu_sort_amd import sharded
     n = 300007
     keys = oracle.gen_zipf(n, seed=1)
     vals = oracle.gen_enumerated(n) if pairs else None
-    srt = sharded.ShardedSorter(n, pairs, cuda, local_algo=algo)
+    if algo == "pipeline-msb":
+        srt = sharded.ShardedSorter(n, pairs, cuda, pipeline="msb")
+    else:
+        srt = sharded.ShardedSorter(n, pairs, cuda, local_algo=algo, pipeline="partition")
     dk = to_dev(keys, cuda)
     dv = to_dev(vals, cuda) if pairs else None
     chk = srt.input_checksum(dk)
@@ -60,3 +63,86 @@ def test_sharded_sorter_single_rank(gs, cuda, oracle, pairs, algo):
     assert ok
     if pairs:
         assert oracle.msb_check_pairs_enumerated(keys, to_u32(sk)[:n], to_u32(sv)[:n]) == 0
+    assert srt.last["pipeline"] == ("msb" if algo == "pipeline-msb" else "partition")
+
+
+@pytest.mark.parametrize("n", [0, 1, 777, 8192, 100003, (1 << 21) + 11])
+def test_first_pass_groups_by_top_byte(gs, cuda, oracle, n):
+    """gs_msb_first_pass_u32 = level 0 of the MSB sort on its own: stable partition on the top byte + sizes."""
+    from gpu_sort_amd import sharded
+    ops = sharded.DeviceOps(cuda)
+    keys, vals = oracle.gen_uniform(n, seed=9), oracle.gen_enumerated(n)
+    temp = torch.empty(ops.temp_bytes(max(n, 1), True), dtype=torch.uint8, device=cuda)
+    ko, vo = ops.empty(n), ops.empty(n)
+    counts = ops.first_pass(to_dev(keys, cuda), to_dev(vals, cuda), n, temp, ko, vo).cpu().numpy()
+    torch.cuda.synchronize()
+    assert np.array_equal(counts, np.bincount(keys >> np.uint32(24), minlength=256))
+    order = np.argsort(keys >> np.uint32(24), kind="stable")
+    assert np.array_equal(to_u32(ko)[:n], keys[order]) and np.array_equal(to_u32(vo)[:n], vals[order])
+
+
+def _emulate_receive(oracle, ops, cuda, shards, byte_lo, byte_hi, pairs):
+    """What rank `r` owning top bytes [byte_lo, byte_hi) receives from the given source shards."""
+    rk, rv, pieces, base = [], [], [], 0
+    for keys in shards:
+        n = keys.size
+        vals = np.arange(base, base + n, dtype=np.uint32)
+        temp = torch.empty(ops.temp_bytes(max(n, 1), pairs), dtype=torch.uint8, device=cuda)
+        ko, vo = ops.empty(n), ops.empty(n)
+        counts = ops.first_pass(to_dev(keys, cuda), to_dev(vals, cuda) if pairs else None, n, temp, ko,
+                                vo if pairs else None).cpu().numpy()
+        torch.cuda.synchronize()
+        start = int(counts[:byte_lo].sum()); stop = int(counts[:byte_hi].sum())
+        rk.append(to_u32(ko)[start:stop].copy())
+        if pairs:
+            rv.append(to_u32(vo)[start:stop].copy())
+        c = np.zeros(256, np.uint64); c[byte_lo:byte_hi] = counts[byte_lo:byte_hi]
+        pieces.append(c)
+        base += n
+    return np.concatenate(rk), (np.concatenate(rv) if pairs else None), np.stack(pieces)
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+@pytest.mark.parametrize("case", ["uniform8", "zipf3", "tiny", "one_byte", "uneven", "empty_range"])
+def test_finish_on_received_pieces(gs, cuda, oracle, pairs, case):
+    """gs_msb_finish_u32: buckets arriving in one piece per source rank are sorted where they lie."""
+    from gpu_sort_amd import sharded
+    ops = sharded.DeviceOps(cuda)
+    if case == "uniform8":
+        shards = [oracle.gen_uniform(150001 + 1000 * i, seed=i) for i in range(8)]; lo, hi = 64, 96
+    elif case == "zipf3":
+        shards = [oracle.gen_zipf(400000, seed=0, start=i * 400000) for i in range(3)]; lo, hi = 0, 128
+    elif case == "tiny":
+        shards = [oracle.gen_uniform(300 + i, seed=20 + i) for i in range(4)]; lo, hi = 0, 256
+    elif case == "one_byte":                      # a single hot bucket spread over the sources
+        shards = [(oracle.gen_uniform(120000, seed=30 + i) & np.uint32(0x00FFFFFF)) | np.uint32(0x7B000000) for i in range(5)]
+        lo, hi = 0x7B, 0x7C
+    elif case == "uneven":                        # sources of very different size, one of them empty
+        shards = [oracle.gen_uniform(m, seed=40 + i) for i, m in enumerate([500000, 0, 17, 90001])]; lo, hi = 10, 200
+    else:
+        shards = [oracle.gen_uniform(50000, seed=50 + i) & np.uint32(0x0FFFFFFF) for i in range(2)]; lo, hi = 128, 256
+    all_keys = np.concatenate(shards)
+    rk, rv, pieces = _emulate_receive(oracle, ops, cuda, shards, lo, hi, pairs)
+    m = rk.size
+    mine = all_keys[(all_keys >> np.uint32(24) >= lo) & (all_keys >> np.uint32(24) < hi)]
+    assert m == mine.size == int(pieces.sum())
+    temp = torch.empty(ops.temp_bytes(max(m, 1), pairs, len(shards)), dtype=torch.uint8, device=cuda)
+    dk, out_k = to_dev(rk, cuda) if m else ops.empty(0), ops.empty(m)
+    dv = (to_dev(rv, cuda) if m else ops.empty(0)) if pairs else None
+    out_v = ops.empty(m) if pairs else None
+    sk, sv = ops.finish(dk, dv, m, out_k, out_v, pieces, temp)
+    torch.cuda.synchronize()
+    assert np.array_equal(to_u32(sk)[:m], np.sort(mine))
+    if pairs:
+        got_v = to_u32(sv)[:m]
+        assert np.array_equal(all_keys[got_v], to_u32(sk)[:m])        # every value still names its key
+        assert np.unique(got_v).size == m
+
+
+def test_finish_rejects_inconsistent_piece_table(gs, cuda):
+    from gpu_sort_amd import sharded
+    ops = sharded.DeviceOps(cuda)
+    temp = torch.empty(ops.temp_bytes(1000, False, 2), dtype=torch.uint8, device=cuda)
+    pieces = np.zeros((2, 256), np.uint64); pieces[0, 3] = 400; pieces[1, 3] = 500     # 900 != 1000
+    with pytest.raises(gs.GpuSortError):
+        ops.finish(ops.empty(1000), None, 1000, ops.empty(1000), None, pieces, temp)

@@ -38,8 +38,28 @@ class NumpyOps:
             vals_out[:n] = torch.from_numpy(self._u32(vals, n)[order].view(np.int32))
         return torch.from_numpy(np.bincount(d, minlength=world).astype(np.int64))
 
-    def temp_bytes(self, n, pairs):
+    def temp_bytes(self, n, pairs, world=1):
         return 256
+
+    def first_pass(self, keys, vals, n, temp, keys_out, vals_out):
+        k = self._u32(keys, n)
+        order = np.argsort(k >> np.uint32(24), kind="stable")
+        keys_out[:n] = torch.from_numpy(k[order].view(np.int32))
+        if vals is not None:
+            vals_out[:n] = torch.from_numpy(self._u32(vals, n)[order].view(np.int32))
+        return torch.from_numpy(np.bincount(k >> np.uint32(24), minlength=256).astype(np.int64))
+
+    def finish(self, keys, vals, m, keys_out, vals_out, piece_counts, temp):
+        # what gs_msb_finish_u32 is told must describe the buffer: source after source, top bytes ascending
+        k = self._u32(keys, m)
+        assert int(piece_counts.sum()) == m
+        pos = 0
+        for s in range(piece_counts.shape[0]):
+            for b in np.nonzero(piece_counts[s])[0]:
+                c = int(piece_counts[s][b])
+                assert np.all(k[pos:pos + c] >> np.uint32(24) == b), "piece table does not match the received buffer"
+                pos += c
+        return self.local_sort(keys, vals, m, keys_out, vals_out, temp)
 
     def local_sort(self, keys, vals, n, keys_alt, vals_alt, temp, algo="lsb"):
         k = self._u32(keys, n)
@@ -66,7 +86,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, dist_kind, pairs, out_dir):
+def _worker(rank, world, port, n, dist_kind, pairs, out_dir, pipeline="msb"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -76,7 +96,7 @@ def _worker(rank, world, port, n, dist_kind, pairs, out_dir):
     gen = {"uniform": O.gen_uniform, "zipf": O.gen_zipf}[dist_kind]
     keys = gen(n, 0, rank * n) if dist_kind != "const" else np.full(n, 7, np.uint32)
     vals = (O.gen_enumerated(n, rank * n)) if pairs else None
-    srt = sharded.ShardedSorter(n, pairs, torch.device("cpu"), ops=NumpyOps())
+    srt = sharded.ShardedSorter(n, pairs, torch.device("cpu"), ops=NumpyOps(), pipeline=pipeline)
     tk = torch.from_numpy(keys.view(np.int32).copy())
     tv = torch.from_numpy(vals.view(np.int32).copy()) if pairs else None
     chk = srt.input_checksum(tk)
@@ -84,6 +104,8 @@ def _worker(rank, world, port, n, dist_kind, pairs, out_dir):
     ok, glob = srt.verify(sk, cnt, chk)
     assert ok, "sharded result fails the global properties"
     assert int(srt.last["send"].sum()) == n and int(srt.last["recv"].sum()) == cnt
+    with open(os.path.join(out_dir, f"p{rank}.txt"), "w") as f:
+        f.write(srt.last["pipeline"])
     np.save(os.path.join(out_dir, f"k{rank}.npy"), sk[:cnt].numpy().view(np.uint32))
     if pairs:
         np.save(os.path.join(out_dir, f"v{rank}.npy"), sv[:cnt].numpy().view(np.uint32))
@@ -91,10 +113,16 @@ def _worker(rank, world, port, n, dist_kind, pairs, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dist_kind,pairs", [(2, "uniform", False), (2, "zipf", True), (4, "uniform", True)])
-def test_sharded_sort_over_gloo(tmp_path, oracle, world, dist_kind, pairs):
+@pytest.mark.parametrize("world,dist_kind,pairs,pipeline", [(2, "uniform", False, "msb"), (2, "zipf", True, "msb"),
+                                                            (4, "uniform", True, "msb"), (2, "uniform", True, "partition"),
+                                                            (4, "zipf", False, "partition")])
+def test_sharded_sort_over_gloo(tmp_path, oracle, world, dist_kind, pairs, pipeline):
     n = 50000
-    mp.spawn(_worker, args=(world, _free_port(), n, dist_kind, pairs, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, dist_kind, pairs, str(tmp_path), pipeline), nprocs=world, join=True)
+    used = {open(tmp_path / f"p{r}.txt").read() for r in range(world)}
+    assert len(used) == 1                                             # every rank took the same pipeline
+    if dist_kind == "uniform":
+        assert used == {pipeline}
     gen = {"uniform": oracle.gen_uniform, "zipf": oracle.gen_zipf}[dist_kind]
     all_keys = np.concatenate([gen(n, 0, r * n) for r in range(world)])
     got = np.concatenate([np.load(tmp_path / f"k{r}.npy") for r in range(world)])
