@@ -103,7 +103,7 @@ def _emulate_receive(oracle, ops, cuda, shards, byte_lo, byte_hi, pairs):
 
 
 @pytest.mark.parametrize("pairs", [False, True])
-@pytest.mark.parametrize("case", ["uniform8", "zipf3", "tiny", "one_byte", "uneven", "empty_range"])
+@pytest.mark.parametrize("case", ["uniform8", "zipf3", "tiny", "one_byte", "uneven", "empty_range", "deep"])
 def test_finish_on_received_pieces(gs, cuda, oracle, pairs, case):
     """gs_msb_finish_u32: buckets arriving in one piece per source rank are sorted where they lie."""
     from gpu_sort_amd import sharded
@@ -119,6 +119,8 @@ def test_finish_on_received_pieces(gs, cuda, oracle, pairs, case):
         lo, hi = 0x7B, 0x7C
     elif case == "uneven":                        # sources of very different size, one of them empty
         shards = [oracle.gen_uniform(m, seed=40 + i) for i, m in enumerate([500000, 0, 17, 90001])]; lo, hi = 10, 200
+    elif case == "deep":                          # two 8M-key buckets in 4 pieces each: a second partition level is needed
+        shards = [oracle.gen_uniform(1 << 22, seed=60 + i) & np.uint32(0x01FFFFFF) for i in range(4)]; lo, hi = 0, 2
     else:
         shards = [oracle.gen_uniform(50000, seed=50 + i) & np.uint32(0x0FFFFFFF) for i in range(2)]; lo, hi = 128, 256
     all_keys = np.concatenate(shards)
