@@ -14,7 +14,7 @@ Names follow the reference:
 """
 from ._lib import (GpuSortError, GS_KEY_U32, GS_KEY_I32, GS_KEY_F32, GS_KEY_U64, GS_KEY_I64, GS_KEY_F64, GS_GEN_UNIFORM, GS_GEN_ZIPF,
                    GS_GEN_ENTROPY_AND, GS_GEN_ENUMERATED, LIB_PATH, lib, KernelProfile)
-from .lsb import DoubleBuffer, DeviceRadixSort, sortKeysGPU, sortPairsGPU, lsb_pass_kernels
+from .lsb import DoubleBuffer, DeviceRadixSort, DeviceSegmentedRadixSort, sortKeysGPU, sortPairsGPU, lsb_pass_kernels
 from .datagen import (generate_random_keys, generate_uniform_keys, generate_zipf_keys, generate_enumerated_values,
                       check_sorted, check_pairs_enumerated)
 from .msb import RDXSRT_SortedSequence, rdxsrt_unstable_sort, rdxsrt_unstable_sort_keys, rdxsrt_unstable_sort_pairs

@@ -83,11 +83,12 @@ static inline uint32_t msb_max_buckets(uint64_t n, bool has_values, uint32_t ext
 {
     return (uint32_t)(n / msb_class_cap(msb_num_classes(has_values) - 1)) + RADIX + 1 + extra;
 }
-static inline uint32_t msb_max_tasks(uint64_t n, bool has_values, uint32_t extra = 0)
+// `extra_tasks`: segments of a segmented sort (each may be one task)
+static inline uint32_t msb_max_tasks(uint64_t n, bool has_values, uint32_t extra = 0, uint32_t extra_tasks = 0)
 {
     // a task is either >= MSB_MERGE keys or is followed by something that did not fit: <= 2n/MERGE,
     // plus up to 256 per partitioned bucket
-    return (uint32_t)(2 * n / MSB_MERGE) + msb_max_buckets(n, has_values, extra) + 2 * RADIX;
+    return (uint32_t)(2 * n / MSB_MERGE) + msb_max_buckets(n, has_values, extra) + 2 * RADIX + extra_tasks;
 }
 // tiles of a level: n / TILE full ones + one ragged tile per bucket, padded to whole chunks + one spare chunk
 static inline uint32_t msb_max_tiles(uint64_t n, bool has_values, uint32_t extra = 0)
@@ -95,20 +96,20 @@ static inline uint32_t msb_max_tiles(uint64_t n, bool has_values, uint32_t extra
     const uint64_t t = n / MSB_TILE + msb_max_buckets(n, has_values, extra) + 1;
     return (uint32_t)((t / MSB_WAVES + 2) * MSB_WAVES);
 }
-static size_t msb_ws_bytes(uint64_t n, bool has_values, uint32_t extra = 0)
+static size_t msb_ws_bytes(uint64_t n, bool has_values, uint32_t extra = 0, uint32_t extra_tasks = 0)
 {
-    const size_t mb = msb_max_buckets(n, has_values, extra), mt = msb_max_tasks(n, has_values, extra),
+    const size_t mb = msb_max_buckets(n, has_values, extra), mt = msb_max_tasks(n, has_values, extra, extra_tasks),
                  ml = msb_max_tiles(n, has_values, extra);
     return align256(5 * sizeof(MsbLevel)) + 2 * align256(mb * sizeof(MsbBucket)) + align256(ml * sizeof(MsbTile)) +
            align256(mb * RADIX * sizeof(uint32_t)) + align256((size_t)RADIX * (ml / MSB_WAVES) * sizeof(uint32_t)) +
            align256(ml * RADIX * sizeof(uint16_t)) + MSB_NCLASS * align256(mt * sizeof(MsbTask)) +
            align256((size_t)extra * sizeof(MsbPiece));
 }
-static MsbWs msb_carve(void *temp, uint64_t n, bool has_values, uint32_t extra = 0)
+static MsbWs msb_carve(void *temp, uint64_t n, bool has_values, uint32_t extra = 0, uint32_t extra_tasks = 0)
 {
     MsbWs ws;
     ws.max_buckets = msb_max_buckets(n, has_values, extra);
-    ws.max_tasks = msb_max_tasks(n, has_values, extra);
+    ws.max_tasks = msb_max_tasks(n, has_values, extra, extra_tasks);
     ws.max_tiles = msb_max_tiles(n, has_values, extra);
     ws.stride = ws.max_tiles / MSB_WAVES;
     char *c = (char *)temp;
@@ -178,8 +179,10 @@ struct DigitSel {
     int shift;                  // used when remap == nullptr
     const uint8_t *remap;       // destination of each top-bits bin, or nullptr
     int rshift;
-    int f32_in;
+    int f32_in;                 // key transform of the remap lookup, and of the keys themselves when tw_in is set
     uint32_t xor_in;
+    int bits;                   // digit width (8; fewer in the last pass of a segmented sort on a bit sub-range)
+    int tw_in;                  // the keys are still raw: transform them on load (first pass of a segmented sort)
 };
 constexpr int SHARD_MAX_BITS = 12;   // 4096 bins of the key space
 // `tab`: the remap table staged in LDS by load_remap (global gathers of a 4 KiB table cost more
@@ -197,7 +200,7 @@ template <bool REMAP>
 __device__ __forceinline__ uint32_t msb_digit(const DigitSel &ds, const uint8_t *tab, uint32_t k)
 {
     if (REMAP) return tab[twiddle_in(k, ds.f32_in, ds.xor_in) >> ds.rshift];
-    return __builtin_amdgcn_ubfe(k, (uint32_t)ds.shift, 8u);
+    return __builtin_amdgcn_ubfe(k, (uint32_t)ds.shift, (uint32_t)ds.bits);
 }
 
 // M3 as an upsweep: one block per chunk of 8 level tiles, one WAVE per tile (wave-private LDS
@@ -220,7 +223,10 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int 
         if (g < ntiles) {
             const MsbTile T = ws.tiles[g];
             const uint32_t *p = src + T.lo;
-            auto count = [&](uint32_t k) { hist_add(my, msb_digit<REMAP>(ds, tab, k)); };
+            auto count = [&](uint32_t k) {
+                if (!REMAP && ds.tw_in) k = twiddle_in(k, ds.f32_in, ds.xor_in);
+                hist_add(my, msb_digit<REMAP>(ds, tab, k));
+            };
             if (T.valid == (uint32_t)MSB_TILE) {
 #pragma unroll
                 for (int j = 0; j < MSB_TILE / WAVE; j += BATCH) {
@@ -417,6 +423,10 @@ __device__ __forceinline__ void msb_scatter_tile(ScatterSmem<HAS_VALUES, REMAP> 
             const uint32_t off = (FULL ? idx : (idx < valid ? idx : valid - 1u)) * 4u;
             val[i] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(pv) + off);
         }
+    }
+    if (!REMAP && ds.tw_in) {   // raw keys (segmented sort, first pass): they travel transformed from here on
+#pragma unroll
+        for (int i = 0; i < MSB_KPT; ++i) key[i] = twiddle_in(key[i], ds.f32_in, ds.xor_in);
     }
     // global start of this tile's slice of every sub-bucket (wave 0): cursor + E(tile, d)
     uint32_t tbase[4] = {0, 0, 0, 0};
@@ -633,7 +643,9 @@ struct LocalSmem {
 // keys are in registers while they are needed), so a 17408-key range costs 68 KiB of LDS and two
 // 1024-thread workgroups fit a CU.  The next task's keys are requested before the current one is
 // stored (their registers are free by then).
-template <int THREADS, int KPT, bool HAS_VALUES>
+// STABLE (segmented sort): no order-free pass -- every pass is a stable ballot-match pass -- and the task's
+// bits start at bit `pad` (= begin_bit) of the key.
+template <int THREADS, int KPT, bool HAS_VALUES, bool STABLE = false>
 __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_sort_kernel(
     MsbWs ws, int L, int cls, const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k, const uint32_t *__restrict__ src_v,
     uint32_t *__restrict__ dst_v, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out)
@@ -682,8 +694,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
             }
         }
         const uint32_t B = T.sort_bits;
-        const uint32_t b1 = B < (uint32_t)LOCAL_B1 ? B : (uint32_t)LOCAL_B1;
-        {   // ---- first pass: shared histogram of 2^b1 bins, order-free ranks
+        const uint32_t b1 = STABLE ? 0u : (B < (uint32_t)LOCAL_B1 ? B : (uint32_t)LOCAL_B1);
+        bool in_regs = STABLE;                            // the keys of the first stable pass are still in registers
+        if (!STABLE) {   // ---- first pass: shared histogram of 2^b1 bins, order-free ranks
             const uint32_t nbins = 1u << b1, mask1 = nbins - 1u;
             for (uint32_t j = tid; j < nbins; j += THREADS) sm.hist[j] = 0;
             __syncthreads();
@@ -759,10 +772,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
             __syncthreads();
         }
         // ---- remaining bits: stable passes of <= 8 bits
-        uint32_t rem = B - b1, np = (rem + 7u) / 8u, shift = b1;
+        uint32_t rem = B - b1, np = (rem + 7u) / 8u, shift = b1 + (STABLE ? T.pad : 0u);
         while (rem) {
             const uint32_t b = (rem + np - 1u) / np, nd = 1u << b;
             const uint32_t wbase = fresh(wbase0);
+            if (!in_regs) {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {               // back into registers in position order
                 const uint32_t idx = wbase + i * WAVE;
@@ -775,6 +789,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
                 if (idx >= T.size) key[i] = 0xffffffffu;  // the pads: last in position and largest in every digit
             }
             __syncthreads();                              // then the counters may overwrite the buffer
+            }
+            in_regs = false;
 #pragma unroll
             for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
             auto rank_pass = [&](auto width) {
@@ -916,13 +932,13 @@ __global__ void shard_counts_kernel(const uint32_t *__restrict__ row, uint32_t n
 
 // ------------------------------------------------------------------- host --
 
-template <bool HAS_VALUES>
+template <bool HAS_VALUES, bool STABLE = false>
 static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uint32_t *sk, uint32_t *dk, const uint32_t *sv,
                                uint32_t *dv, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out, hipStream_t s)
 {
     KernelTimer kt(GS_K_MSB_LOCAL_SORT, s);
     const uint32_t grid = bound < MSB_MAX_GRID ? bound : MSB_MAX_GRID;   // grid-stride over the task list
-#define GS_LS(C, HV) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV>), dim3(grid), \
+#define GS_LS(C, HV) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV, STABLE>), dim3(grid), \
                                         dim3(msb_class_threads(C)), 0, s, ws, L, C, sk, dk, sv, dv, f32_in, xor_in, f32_out, xor_out)
     GS_LS(0, HAS_VALUES);
     GS_LS(1, HAS_VALUES);
@@ -944,7 +960,7 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
     uint32_t *d_keys = buf_k[0], *d_vals = buf_v[0];
     for (int L = 1; L <= 3; ++L) {
         const int shift = 24 - 8 * L;
-        const DigitSel dsel{shift, nullptr, 0, 0, 0u};
+        const DigitSel dsel{shift, nullptr, 0, 0, 0u, 8, 0};
         uint32_t *sk = buf_k[L & 1], *dk = buf_k[(L + 1) & 1];
         uint32_t *sv = buf_v[L & 1], *dv = buf_v[(L + 1) & 1];
         const bool in_pieces = npieces != 0 && L == 1;
@@ -1054,6 +1070,46 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
     return err;
 }
 
+// ---- segmented sort (cub::DeviceSegmentedRadixSort, dispatch_radix_sort.cuh:321-432)
+// Segments that fit a workgroup become stable local-sort tasks; the others become the buckets of ONE level
+// that is partitioned once per 8-bit digit, least significant first, with the level machinery above.
+__global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *__restrict__ seg_begin,
+                                                           const int *__restrict__ seg_end, uint32_t nseg, int nclass,
+                                                           uint32_t sort_bits, uint32_t shift0)
+{
+    const uint32_t cap_max = msb_class_cap(nclass - 1);
+    for (uint32_t base = blockIdx.x * blockDim.x; base < nseg; base += gridDim.x * blockDim.x) {
+        const uint32_t sg = base + threadIdx.x;
+        uint32_t b = 0, size = 0;
+        if (sg < nseg) {
+            const int lo = seg_begin[sg], hi = seg_end[sg];
+            if (hi > lo) { b = (uint32_t)lo; size = (uint32_t)(hi - lo); }
+        }
+        int cls = -1;
+        if (size != 0 && size <= cap_max) { cls = 0; while (msb_class_cap(cls) < size) ++cls; }
+        // one global atomic per wave and class
+#pragma unroll
+        for (int c = 0; c < MSB_NCLASS; ++c) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == c);
+            if (m == 0) continue;
+            uint32_t first = 0;
+            if (count_lower_mask(m) == 0 && cls == c) first = atomicAdd(&ws.level[1].task_count[c], (uint32_t)__popcll(m));
+            first = (uint32_t)__shfl((int)first, __builtin_ctzll(m), WAVE);
+            if (cls == c) ws.tasks[c][first + count_lower_mask(m)] = MsbTask{b, size, sort_bits, shift0};
+        }
+        if (size > cap_max) {
+            const uint32_t tiles = (size + MSB_TILE - 1) / MSB_TILE;
+            const unsigned long long old = atomicAdd(&ws.level[1].packed, (1ull << 32) | tiles);
+            ws.buckets[1][(uint32_t)(old >> 32)] = MsbBucket{b, size, (uint32_t)old, tiles};
+        }
+    }
+}
+
+size_t gs_segmented_temp_bytes_impl(uint64_t num_items, int has_values, uint32_t num_segments)
+{
+    return msb_ws_bytes(num_items, has_values != 0, 0, num_segments);
+}
+
 // ---- the MSB path cut at the exchange point of the multi-GPU sort (north_star:
 // "a single RCCL all-to-all after the first digit pass")
 
@@ -1152,6 +1208,76 @@ int gs_msb_finish_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_
     return err;
 }
 
+size_t gs_segmented_temp_bytes(uint64_t num_items, int has_values, uint32_t num_segments)
+{
+    return gs_segmented_temp_bytes_impl(num_items, has_values, num_segments);
+}
+
+int gs_segmented_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], uint32_t *d_vals[2], int *selector,
+                          uint64_t num_items, uint32_t num_segments, const int32_t *d_begin_offsets,
+                          const int32_t *d_end_offsets, int begin_bit, int end_bit, int descending, int key_type, void *stream)
+{
+    if (!selector || (*selector != 0 && *selector != 1) || !d_keys) return hipErrorInvalidValue;
+    if (begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) return hipErrorInvalidValue;
+    if (num_items >= (1ull << 31)) return hipErrorInvalidValue;                  // int offsets
+    if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;
+    if (num_items == 0 || num_segments == 0 || begin_bit == end_bit) return hipSuccess;
+    const bool pairs = d_vals != nullptr;
+    if (!d_begin_offsets || !d_end_offsets) return hipErrorInvalidValue;
+    if (!d_temp || temp_bytes < gs_segmented_temp_bytes(num_items, pairs, num_segments)) return hipErrorInvalidValue;
+    if (!d_keys[0] || !d_keys[1] || (pairs && (!d_vals[0] || !d_vals[1]))) return hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const MsbWs ws = msb_carve(d_temp, num_items, pairs, 0, num_segments);
+    const int nclass = msb_num_classes(pairs);
+    const int num_bits = end_bit - begin_bit, passes = (num_bits + RADIX_BITS - 1) / RADIX_BITS;
+    const int sel = *selector, fin = sel ^ (passes & 1);                         // one flip per pass, like gs_lsb_sort_u32
+    PassParams tw{};
+    lsb_twiddle_masks(key_type, descending, true, true, tw);
+
+    hipError_t e = hipMemsetAsync(ws.level, 0, 5 * sizeof(MsbLevel), s);
+    if (e != hipSuccess) return (int)e;
+    { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
+      const uint32_t g = (num_segments + 255u) / 256u;
+      hipLaunchKernelGGL(seg_classify_kernel, dim3(g < 4096u ? g : 4096u), dim3(256), 0, s, ws, d_begin_offsets, d_end_offsets,
+                         num_segments, nclass, (uint32_t)num_bits, (uint32_t)begin_bit); }
+    // small segments: one stable local sort each, straight into the final buffer
+    if (pairs) launch_local_sorts<true, true>(ws, 1, num_segments, d_keys[sel], d_keys[fin], d_vals[sel], d_vals[fin], tw.f32_in,
+                                              tw.xor_in, tw.f32_out, tw.xor_out, s);
+    else launch_local_sorts<false, true>(ws, 1, num_segments, d_keys[sel], d_keys[fin], nullptr, nullptr, tw.f32_in, tw.xor_in,
+                                         tw.f32_out, tw.xor_out, s);
+    // large segments: `passes` stable partitions of the same bucket list, 8 bits at a time from begin_bit
+    const uint32_t max_b = ws.max_buckets;
+    const uint32_t tiles_ub = (uint32_t)(num_items / MSB_TILE) + max_b;
+    { KernelTimer kt(GS_K_MSB_HISTOGRAM, s);
+      hipLaunchKernelGGL(msb_expand_kernel, dim3(max_b < 4096u ? max_b : 4096u), dim3(256), 0, s, ws, 1); }
+    const bool any_tw = tw.f32_in || tw.xor_in;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = begin_bit + p * RADIX_BITS;
+        const int bits = (end_bit - shift < RADIX_BITS) ? end_bit - shift : RADIX_BITS;
+        const bool first = p == 0, last = p == passes - 1;
+        const DigitSel dsel{shift, nullptr, 0, tw.f32_in, tw.xor_in, bits, (first && any_tw) ? 1 : 0};
+        uint32_t *sk = d_keys[sel ^ (p & 1)], *dk = d_keys[sel ^ ((p + 1) & 1)];
+        const uint32_t *sv = pairs ? d_vals[sel ^ (p & 1)] : nullptr;
+        uint32_t *dv = pairs ? d_vals[sel ^ ((p + 1) & 1)] : nullptr;
+        { KernelTimer kt(GS_K_MSB_HISTOGRAM, s);
+          const uint32_t hg_ub = tiles_ub / MSB_WAVES + 1;
+          hipLaunchKernelGGL(msb_upsweep_kernel<false>, dim3(hg_ub < MSB_MAX_GRID ? hg_ub : MSB_MAX_GRID), dim3(MSB_THREADS), 0, s, ws,
+                             1, (const uint32_t *)sk, dsel);
+          hipLaunchKernelGGL(msb_scan_kernel, dim3(RADIX), dim3(1024), 0, s, ws, 1); }
+        { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
+          hipLaunchKernelGGL(msb_classify_kernel<true>, dim3(max_b < 4096u ? max_b : 4096u), dim3(256), 0, s, ws, 1,
+                             (const uint32_t *)nullptr, nclass); }
+        { KernelTimer kt(GS_K_MSB_PARTITION, s);
+          if (pairs) { if (last) launch_scatter<true, false, true>(ws, 1, tiles_ub, max_b, false, sk, dk, sv, dv, dsel, tw.f32_out, tw.xor_out, s);
+                       else launch_scatter<true, false, false>(ws, 1, tiles_ub, max_b, false, sk, dk, sv, dv, dsel, 0, 0u, s); }
+          else { if (last) launch_scatter<false, false, true>(ws, 1, tiles_ub, max_b, false, sk, dk, sv, dv, dsel, tw.f32_out, tw.xor_out, s);
+                 else launch_scatter<false, false, false>(ws, 1, tiles_ub, max_b, false, sk, dk, sv, dv, dsel, 0, 0u, s); }
+        }
+    }
+    *selector = fin;
+    return (int)hipGetLastError();
+}
+
 int gs_shard_histogram_u32(const uint32_t *d_keys, uint64_t num_items, int bits, uint64_t *d_hist, int key_type,
                            void *stream)
 {
@@ -1196,7 +1322,7 @@ int gs_shard_partition_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_ke
     const MsbWs ws = msb_carve((char *)d_temp + align256(lsb_temp_bytes(num_items)), num_items, pairs);
     PassParams tw{};
     lsb_twiddle_masks(key_type, 0, true, true, tw);
-    const DigitSel dsel{0, d_dest_of_bin, 32 - bits, tw.f32_in, tw.xor_in};
+    const DigitSel dsel{0, d_dest_of_bin, 32 - bits, tw.f32_in, tw.xor_in, 8, 0};
     const uint32_t tiles = (n + MSB_TILE - 1) / MSB_TILE;
     const uint32_t grid = tiles;   // the tile count is known here: one tile per block, dispatched in order
     (void)d_bin_hist;              // per-tile counts are needed now: the keys are always read once more

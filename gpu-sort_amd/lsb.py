@@ -179,6 +179,70 @@ class DeviceRadixSort:
                                      end_bit, True, stream, key_type)
 
 
+class DeviceSegmentedRadixSort:
+    """cub::DeviceSegmentedRadixSort (lsb/cub/cub/device/device_segmented_radix_sort.cuh), DoubleBuffer form:
+    segment i is [d_begin_offsets[i], d_end_offsets[i]) (int32 device tensors; one offsets tensor of
+    num_segments + 1 entries can serve as both, the end offsets being offsets[1:]).  Two-phase like CUB."""
+
+    @staticmethod
+    def _sort(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, num_segments, d_begin_offsets, d_end_offsets,
+              begin_bit, end_bit, descending, stream, key_type):
+        has_values = d_values is not None
+        need = lib.gs_segmented_temp_bytes(num_items, int(has_values), num_segments)
+        if d_temp_storage is None:
+            return need
+        if end_bit is None:
+            end_bit = 32
+        if key_type is None:
+            key_type = _KEY_TYPES.get(d_keys.d_buffers[0].dtype, _lib.GS_KEY_U32)
+        for b in d_keys.d_buffers:
+            _check_buf(b, num_items, "d_keys")
+        for o in (d_begin_offsets, d_end_offsets):
+            if not isinstance(o, torch.Tensor) or o.dtype != torch.int32 or not o.is_cuda or o.numel() < num_segments:
+                raise ValueError("segment offsets: expected int32 device tensors of >= num_segments entries")
+        keys = (C.c_void_p * 2)(d_keys.d_buffers[0].data_ptr(), d_keys.d_buffers[1].data_ptr())
+        vals = None
+        if has_values:
+            for b in d_values.d_buffers:
+                _check_buf(b, num_items, "d_values")
+            vals = (C.c_void_p * 2)(d_values.d_buffers[0].data_ptr(), d_values.d_buffers[1].data_ptr())
+        sel = C.c_int(d_keys.selector)
+        err = lib.gs_segmented_sort_u32(C.c_void_p(d_temp_storage.data_ptr()),
+                                        min(temp_storage_bytes, d_temp_storage.numel() * d_temp_storage.element_size()),
+                                        keys, vals, C.byref(sel), num_items, num_segments,
+                                        C.c_void_p(d_begin_offsets.data_ptr()), C.c_void_p(d_end_offsets.data_ptr()),
+                                        begin_bit, end_bit, int(descending), key_type, _stream_ptr(stream))
+        check(err, "gs_segmented_sort_u32")
+        d_keys.selector = sel.value
+        if has_values:
+            d_values.selector = sel.value
+        return need
+
+    @staticmethod
+    def SortKeys(d_temp_storage, temp_storage_bytes, d_keys, num_items, num_segments, d_begin_offsets, d_end_offsets,
+                 begin_bit=0, end_bit=None, stream=None, key_type=None):
+        return DeviceSegmentedRadixSort._sort(d_temp_storage, temp_storage_bytes, d_keys, None, num_items, num_segments,
+                                              d_begin_offsets, d_end_offsets, begin_bit, end_bit, False, stream, key_type)
+
+    @staticmethod
+    def SortKeysDescending(d_temp_storage, temp_storage_bytes, d_keys, num_items, num_segments, d_begin_offsets,
+                           d_end_offsets, begin_bit=0, end_bit=None, stream=None, key_type=None):
+        return DeviceSegmentedRadixSort._sort(d_temp_storage, temp_storage_bytes, d_keys, None, num_items, num_segments,
+                                              d_begin_offsets, d_end_offsets, begin_bit, end_bit, True, stream, key_type)
+
+    @staticmethod
+    def SortPairs(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, num_segments, d_begin_offsets,
+                  d_end_offsets, begin_bit=0, end_bit=None, stream=None, key_type=None):
+        return DeviceSegmentedRadixSort._sort(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, num_segments,
+                                              d_begin_offsets, d_end_offsets, begin_bit, end_bit, False, stream, key_type)
+
+    @staticmethod
+    def SortPairsDescending(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, num_segments, d_begin_offsets,
+                            d_end_offsets, begin_bit=0, end_bit=None, stream=None, key_type=None):
+        return DeviceSegmentedRadixSort._sort(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, num_segments,
+                                              d_begin_offsets, d_end_offsets, begin_bit, end_bit, True, stream, key_type)
+
+
 def _timed(fn):
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()

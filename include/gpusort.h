@@ -147,6 +147,20 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes,
  * is issued by the host between these calls (no reference
  * counterpart -- the reference is single-GPU).                               */
 
+/* cub::DeviceSegmentedRadixSort (lsb/cub/cub/device/device_segmented_radix_sort.cuh:77-861;
+ * DeviceSegmentedRadixSortKernel, dispatch_radix_sort.cuh:321-432): every segment
+ * [d_begin_offsets[i], d_end_offsets[i]) of the keys (and values) is sorted on its own, stably,
+ * on bits [begin_bit, end_bit); segments must not overlap, empty ones are fine, and positions
+ * outside every segment are not written.  DoubleBuffer semantics as gs_lsb_sort_u32 (both
+ * halves may be clobbered, the result is d_keys[*selector] after the call).  num_items < 2^31.
+ * Segments that fit one workgroup (<= 17408 keys, 9216 pairs) cost one read and one write; the
+ * larger ones are partitioned together, one 8-bit digit per pass.                       */
+size_t gs_segmented_temp_bytes(uint64_t num_items, int has_values, uint32_t num_segments);
+int gs_segmented_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], uint32_t *d_vals[2],
+                          int *selector, uint64_t num_items, uint32_t num_segments,
+                          const int32_t *d_begin_offsets, const int32_t *d_end_offsets, int begin_bit,
+                          int end_bit, int descending, int key_type, void *stream);
+
 /* The MSB path cut at the exchange point (north_star: "a single RCCL all-to-all after the
  * first digit pass"): gs_msb_first_pass_u32 is the top-byte partition on its own -- keys (and
  * values) leave grouped by top byte in d_*_out, in their order-preserving u32 form, and

@@ -5,6 +5,7 @@
 //
 //   gpusort::DoubleBuffer<T>                      <- cub::DoubleBuffer<T>      lsb/cub/cub/util_type.cuh:785-817
 //   gpusort::DeviceRadixSort::SortKeys/...        <- cub::DeviceRadixSort      lsb/cub/cub/device/device_radix_sort.cuh:248,595,754
+//   gpusort::DeviceSegmentedRadixSort::Sort*      <- cub::DeviceSegmentedRadixSort lsb/cub/cub/device/device_segmented_radix_sort.cuh
 //   gpusort::NullType                             <- cub::NullType
 //   rdxsrt_unstable_sort<K,V,IndexT>(...)         <- msb/src/sort/gpu_radix_sort.h:197
 //   rdxsrt_unstable_sort_keys / _pairs            <- msb/src/sort/gpu_radix_sort.h:511,544
@@ -168,6 +169,75 @@ struct DeviceRadixSort {
     {
         return Dispatch<KeyT, ValueT>(d_temp_storage, temp_storage_bytes, d_keys, &d_values, num_items, begin_bit,
                                       end_bit, true, stream);
+    }
+};
+
+// cub::DeviceSegmentedRadixSort, DoubleBuffer overloads (lsb/cub/cub/device/device_segmented_radix_sort.cuh:
+// 266-289, 450-473, 607-629, 779-801): 32-bit keys, 32-bit values, int offsets.
+struct DeviceSegmentedRadixSort {
+    template <typename KeyT, typename ValueT>
+    static hipError_t Dispatch(void *d_temp_storage, size_t &temp_storage_bytes, DoubleBuffer<KeyT> &d_keys,
+                               DoubleBuffer<ValueT> *d_values, int num_items, int num_segments, const int *d_begin_offsets,
+                               const int *d_end_offsets, int begin_bit, int end_bit, bool descending, hipStream_t stream)
+    {
+        static_assert(sizeof(KeyT) == 4, "32-bit keys only");
+        static_assert(std::is_same<ValueT, NullType>::value || sizeof(ValueT) == 4, "32-bit values only");
+        const size_t need = gs_segmented_temp_bytes((uint64_t)num_items, d_values != nullptr, (uint32_t)num_segments);
+        if (d_temp_storage == nullptr) {
+            temp_storage_bytes = need;
+            return hipSuccess;
+        }
+        uint32_t *keys[2] = {reinterpret_cast<uint32_t *>(d_keys.d_buffers[0]), reinterpret_cast<uint32_t *>(d_keys.d_buffers[1])};
+        uint32_t *vals[2] = {nullptr, nullptr};
+        if (d_values) {
+            vals[0] = reinterpret_cast<uint32_t *>(d_values->d_buffers[0]);
+            vals[1] = reinterpret_cast<uint32_t *>(d_values->d_buffers[1]);
+        }
+        int sel = d_keys.selector;
+        const int err = gs_segmented_sort_u32(d_temp_storage, temp_storage_bytes, keys, d_values ? vals : nullptr, &sel,
+                                              (uint64_t)num_items, (uint32_t)num_segments, d_begin_offsets, d_end_offsets,
+                                              begin_bit, end_bit, descending ? 1 : 0, KeyTraits<KeyT>::type, stream);
+        if (err == 0) {
+            d_keys.selector = sel;
+            if (d_values) d_values->selector = sel;
+        }
+        return static_cast<hipError_t>(err);
+    }
+    template <typename KeyT>
+    static hipError_t SortKeys(void *d_temp_storage, size_t &temp_storage_bytes, DoubleBuffer<KeyT> &d_keys, int num_items,
+                               int num_segments, const int *d_begin_offsets, const int *d_end_offsets, int begin_bit = 0,
+                               int end_bit = sizeof(KeyT) * 8, hipStream_t stream = 0, bool /*debug_synchronous*/ = false)
+    {
+        return Dispatch<KeyT, NullType>(d_temp_storage, temp_storage_bytes, d_keys, nullptr, num_items, num_segments,
+                                        d_begin_offsets, d_end_offsets, begin_bit, end_bit, false, stream);
+    }
+    template <typename KeyT>
+    static hipError_t SortKeysDescending(void *d_temp_storage, size_t &temp_storage_bytes, DoubleBuffer<KeyT> &d_keys,
+                                         int num_items, int num_segments, const int *d_begin_offsets,
+                                         const int *d_end_offsets, int begin_bit = 0, int end_bit = sizeof(KeyT) * 8,
+                                         hipStream_t stream = 0, bool /*debug_synchronous*/ = false)
+    {
+        return Dispatch<KeyT, NullType>(d_temp_storage, temp_storage_bytes, d_keys, nullptr, num_items, num_segments,
+                                        d_begin_offsets, d_end_offsets, begin_bit, end_bit, true, stream);
+    }
+    template <typename KeyT, typename ValueT>
+    static hipError_t SortPairs(void *d_temp_storage, size_t &temp_storage_bytes, DoubleBuffer<KeyT> &d_keys,
+                                DoubleBuffer<ValueT> &d_values, int num_items, int num_segments, const int *d_begin_offsets,
+                                const int *d_end_offsets, int begin_bit = 0, int end_bit = sizeof(KeyT) * 8,
+                                hipStream_t stream = 0, bool /*debug_synchronous*/ = false)
+    {
+        return Dispatch<KeyT, ValueT>(d_temp_storage, temp_storage_bytes, d_keys, &d_values, num_items, num_segments,
+                                      d_begin_offsets, d_end_offsets, begin_bit, end_bit, false, stream);
+    }
+    template <typename KeyT, typename ValueT>
+    static hipError_t SortPairsDescending(void *d_temp_storage, size_t &temp_storage_bytes, DoubleBuffer<KeyT> &d_keys,
+                                          DoubleBuffer<ValueT> &d_values, int num_items, int num_segments,
+                                          const int *d_begin_offsets, const int *d_end_offsets, int begin_bit = 0,
+                                          int end_bit = sizeof(KeyT) * 8, hipStream_t stream = 0,
+                                          bool /*debug_synchronous*/ = false)
+    {
+        return Dispatch<KeyT, ValueT>(d_temp_storage, temp_storage_bytes, d_keys, &d_values, num_items, num_segments,
+                                      d_begin_offsets, d_end_offsets, begin_bit, end_bit, true, stream);
     }
 };
 

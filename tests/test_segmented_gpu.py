@@ -1,0 +1,149 @@
+"""GPU parity tests of the segmented sort (gs_segmented_sort_u32) through the C ABI.
+
+Model: lsb/cub/test/test_device_radix_sort.cu -- the CUB_SEGMENTED backends (:70, :386-470), segment
+offsets from InitializeSegments (:1092-1100: random cut points, empty segments allowed), the reference
+solution = reverse / std::stable_sort / reverse per segment on the masked bits (:634-693), bit ranges
+full / [1,31) / the two middle bits (:973-995), keys-only and pairs, ascending and descending.
+Expected results: the CPU oracle applied per segment.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import to_dev, to_u32
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected(oracle, keys, offsets, begin_bit, end_bit, desc):
+    ranks = np.arange(keys.size, dtype=np.int64)
+    for lo, hi in zip(offsets[:-1], offsets[1:]):
+        if hi > lo:
+            ranks[lo:hi] = lo + oracle.lsb_reference_ranks(keys[lo:hi], begin_bit, end_bit, desc).astype(np.int64)
+    return ranks
+
+
+def _run(gs, cuda, keys, vals, begin_offs, end_offs, begin_bit=0, end_bit=32, desc=False, key_type=None):
+    n, nseg = keys.size, begin_offs.size
+    dk = gs.DoubleBuffer(to_dev(keys, cuda), torch.full((max(n, 1),), -1, dtype=torch.int32, device=cuda))
+    dv = gs.DoubleBuffer(to_dev(vals, cuda), torch.full((max(n, 1),), -1, dtype=torch.int32, device=cuda)) if vals is not None else None
+    ob = torch.from_numpy(begin_offs.astype(np.int32)).to(cuda)
+    oe = torch.from_numpy(end_offs.astype(np.int32)).to(cuda)
+    S = gs.DeviceSegmentedRadixSort
+    kt = gs.GS_KEY_U32 if key_type is None else key_type
+    if dv is None:
+        fn = S.SortKeysDescending if desc else S.SortKeys
+        nb = fn(None, 0, dk, n, nseg, ob, oe)
+        temp = torch.empty(max(nb, 1), dtype=torch.uint8, device=cuda)
+        fn(temp, nb, dk, n, nseg, ob, oe, begin_bit, end_bit, key_type=kt)
+    else:
+        fn = S.SortPairsDescending if desc else S.SortPairs
+        nb = fn(None, 0, dk, dv, n, nseg, ob, oe)
+        temp = torch.empty(max(nb, 1), dtype=torch.uint8, device=cuda)
+        fn(temp, nb, dk, dv, n, nseg, ob, oe, begin_bit, end_bit, key_type=kt)
+    torch.cuda.synchronize()
+    return to_u32(dk.Current())[:n], (to_u32(dv.Current())[:n] if dv is not None else None), dk
+
+
+def _random_offsets(rng, n, nseg):
+    cuts = np.sort(rng.integers(0, n + 1, size=nseg - 1)) if nseg > 1 else np.zeros(0, np.int64)
+    return np.concatenate([[0], cuts, [n]]).astype(np.int64)
+
+
+@pytest.mark.parametrize("n,nseg", [(1, 1), (1000, 1), (1000, 7), (100003, 1), (100003, 40), (100003, 5000),
+                                    (3000017, 3), (3000017, 257), (3000017, 100000)])
+def test_segments_full_range(gs, cuda, oracle, n, nseg):
+    rng = np.random.default_rng(n + nseg)
+    keys = oracle.gen_uniform(n, seed=nseg) & np.uint32(0xFFF0FFFF)
+    vals = oracle.gen_enumerated(n)
+    offs = _random_offsets(rng, n, nseg)
+    for desc in (False, True):
+        ranks = _expected(oracle, keys, offs, 0, 32, desc)
+        ko, vo, _ = _run(gs, cuda, keys, vals, offs[:-1], offs[1:], desc=desc)
+        assert np.array_equal(vo, ranks.astype(np.uint32)), (n, nseg, desc)       # stable: exactly the reference ranks
+        assert np.array_equal(ko, keys[ranks])
+        ko, _, _ = _run(gs, cuda, keys, None, offs[:-1], offs[1:], desc=desc)
+        assert np.array_equal(ko, keys[ranks])
+
+
+@pytest.mark.parametrize("begin_bit,end_bit", [(1, 31), (15, 17), (0, 8), (24, 32), (5, 20), (12, 12)])
+def test_segments_bit_ranges_and_selector(gs, cuda, oracle, begin_bit, end_bit):
+    n = 700001
+    rng = np.random.default_rng(begin_bit * 37 + end_bit)
+    keys = oracle.gen_uniform(n, seed=5)
+    vals = oracle.gen_enumerated(n)
+    offs = np.concatenate([[0, 0, 10, 3000, 3000, 30000, 400000], _random_offsets(rng, n - 400000, 50)[1:] + 400000])
+    for desc in (False, True):
+        ko, vo, dk = _run(gs, cuda, keys, vals, offs[:-1], offs[1:], begin_bit, end_bit, desc)
+        if begin_bit == end_bit:
+            assert dk.selector == 0 and np.array_equal(ko, keys) and np.array_equal(vo, vals)
+            continue
+        ranks = _expected(oracle, keys, offs, begin_bit, end_bit, desc)
+        assert np.array_equal(vo, ranks.astype(np.uint32)), (begin_bit, end_bit, desc)
+        assert np.array_equal(ko, keys[ranks])
+        assert dk.selector == ((end_bit - begin_bit + 7) // 8) % 2
+
+
+def test_segments_with_gaps_and_separate_offset_arrays(gs, cuda, oracle):
+    """begin/end arrays need not be aliased: gaps between segments are not written (the alternate buffer
+    keeps its fill where the result lands there)."""
+    n = 200000
+    keys = oracle.gen_uniform(n, seed=8)
+    vals = oracle.gen_enumerated(n)
+    begin = np.array([10, 5000, 5000, 60000, 150000], dtype=np.int64)
+    end = np.array([4000, 5000, 50000, 140000, 199990], dtype=np.int64)
+    ko, vo, dk = _run(gs, cuda, keys, vals, begin, end, 0, 24)           # 3 passes: result in the alternate buffer
+    assert dk.selector == 1
+    covered = np.zeros(n, bool)
+    for lo, hi in zip(begin, end):
+        r = lo + oracle.lsb_reference_ranks(keys[lo:hi], 0, 24, False).astype(np.int64)
+        assert np.array_equal(ko[lo:hi], keys[r]) and np.array_equal(vo[lo:hi], r.astype(np.uint32))
+        covered[lo:hi] = True
+    assert np.all(ko[~covered] == np.uint32(0xFFFFFFFF))                  # untouched fill of the alternate buffer
+
+
+def test_segments_signed_and_float_keys(gs, cuda, oracle):
+    n = 300000
+    rng = np.random.default_rng(3)
+    offs = _random_offsets(rng, n, 30)
+    f = rng.standard_normal(n).astype(np.float32)
+    i = rng.integers(-2**31, 2**31, size=n, dtype=np.int64).astype(np.int32)
+    kf, _, _ = _run(gs, cuda, f.view(np.uint32), None, offs[:-1], offs[1:], key_type=gs.GS_KEY_F32)
+    ki, _, _ = _run(gs, cuda, i.view(np.uint32), None, offs[:-1], offs[1:], desc=True, key_type=gs.GS_KEY_I32)
+    for lo, hi in zip(offs[:-1], offs[1:]):
+        assert np.array_equal(kf[lo:hi].view(np.float32), np.sort(f[lo:hi]))
+        assert np.array_equal(ki[lo:hi].view(np.int32), np.sort(i[lo:hi])[::-1])
+
+
+def test_segments_large_properties(gs, cuda):
+    """2^27 keys in 1000 uneven segments + one of 2^26: every segment sorted, multiset preserved (device checks)."""
+    n = 1 << 27
+    keys = gs.generate_uniform_keys(n, seed=1, device=cuda)
+    _, s0, x0 = gs.check_sorted(keys)
+    rng = np.random.default_rng(0)
+    offs = np.concatenate([[0, 1 << 26], (1 << 26) + _random_offsets(rng, n - (1 << 26), 1000)[1:]])
+    ob = torch.from_numpy(offs.astype(np.int32)).to(cuda)
+    dk = gs.DoubleBuffer(keys, torch.empty_like(keys))
+    nseg = offs.size - 1
+    nb = gs.DeviceSegmentedRadixSort.SortKeys(None, 0, dk, n, nseg, ob[:-1], ob[1:])
+    temp = torch.empty(nb, dtype=torch.uint8, device=cuda)
+    gs.DeviceSegmentedRadixSort.SortKeys(temp, nb, dk, n, nseg, ob[:-1], ob[1:], key_type=gs.GS_KEY_U32)
+    out = dk.Current()
+    _, s1, x1 = gs.check_sorted(out)
+    assert (s1, x1) == (s0, x0)
+    desc_pos = torch.nonzero(out[1:].view(torch.int32).to(torch.int64).bitwise_and(0xFFFFFFFF)
+                             < out[:-1].view(torch.int32).to(torch.int64).bitwise_and(0xFFFFFFFF)).flatten().cpu().numpy() + 1
+    assert np.all(np.isin(desc_pos, offs))                                # order only breaks at segment starts
+
+
+def test_segmented_errors(gs, cuda):
+    k = torch.zeros(100, dtype=torch.int32, device=cuda)
+    dk = gs.DoubleBuffer(k, torch.empty_like(k))
+    ob = torch.tensor([0, 50, 100], dtype=torch.int32, device=cuda)
+    temp = torch.empty(1 << 20, dtype=torch.uint8, device=cuda)
+    with pytest.raises(gs.GpuSortError):
+        gs.DeviceSegmentedRadixSort.SortKeys(temp, 16, dk, 100, 2, ob[:-1], ob[1:])          # workspace too small
+    with pytest.raises(gs.GpuSortError):
+        gs.DeviceSegmentedRadixSort.SortKeys(temp, temp.numel(), dk, 100, 2, ob[:-1], ob[1:], 0, 33)
+    with pytest.raises(ValueError):
+        gs.DeviceSegmentedRadixSort.SortKeys(temp, temp.numel(), dk, 100, 2, ob[:-1].to(torch.int64), ob[1:])
