@@ -237,7 +237,21 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int 
                     for (int u = 0; u < BATCH; ++u) count(v[u]);
                 }
             } else {
-                for (uint32_t i = lane; i < T.valid; i += WAVE) count(p[i]);
+                // ragged tile: the same batches from clamped indices (one guarded load per trip would pay one
+                // HBM round trip per 64 keys -- a level can hold tens of thousands of ragged tiles)
+                const uint32_t last = T.valid - 1u;
+#pragma unroll 1
+                for (uint32_t j = 0; j < T.valid; j += BATCH * WAVE) {
+                    uint32_t v[BATCH];
+#pragma unroll
+                    for (int u = 0; u < BATCH; ++u) {
+                        const uint32_t idx = j + u * WAVE + lane;
+                        v[u] = p[idx < last ? idx : last];
+                    }
+#pragma unroll
+                    for (int u = 0; u < BATCH; ++u)
+                        if (j + u * WAVE + lane < T.valid) count(v[u]);
+                }
             }
         }
         __syncthreads();

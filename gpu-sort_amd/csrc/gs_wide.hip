@@ -64,7 +64,21 @@ __global__ __launch_bounds__(W_THREADS) void wide_upsweep_kernel(const K *__rest
         const uint64_t lo = (uint64_t)tile * W_TILE;
         const uint32_t len = (p.n - lo < (uint64_t)W_TILE) ? (uint32_t)(p.n - lo) : (uint32_t)W_TILE;
         const K *src = keys + lo;
-        for (uint32_t i = lane; i < len; i += WAVE) hist_add(my, w_digit(w_twiddle_in<K>(src[i], p.f_in, p.xor_in), p));
+        // batches of 16 loads from clamped indices (a loop of one guarded load per trip is latency-bound)
+        constexpr int GB = 16;
+        const uint32_t last = len - 1u;
+#pragma unroll 1
+        for (uint32_t j = 0; j < len; j += GB * WAVE) {
+            K v[GB];
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                const uint32_t idx = j + u * WAVE + lane;
+                v[u] = src[idx < last ? idx : last];
+            }
+#pragma unroll
+            for (int u = 0; u < GB; ++u)
+                if (j + u * WAVE + lane < len) hist_add(my, w_digit(w_twiddle_in<K>(v[u], p.f_in, p.xor_in), p));
+        }
     }
     __syncthreads();
     if (tid < RADIX) {
