@@ -14,7 +14,9 @@
 // Supported key types: unsigned int, int, float (the graded configurations are u32) and,
 // through the DoubleBuffer overloads, unsigned long long, long long, double; value type:
 // any 4- or 8-byte trivially copyable type or NullType.  The plain-pointer (copy)
-// overloads and the MSB entry points are 32-bit only.
+// overloads are 32-bit only.  rdxsrt_unstable_sort with 64-bit keys or values is served by
+// the wide LSB sort (gs_lsb_sort_wide): the hybrid MSB kernels are 32-bit, and a stable result
+// is one of the results an unstable sort may return.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -276,9 +278,27 @@ RDXSRT_SortedSequence<KeyT, ValueT> rdxsrt_unstable_sort(KeyT *dev_keys, ValueT 
                                                          RDXSRT_GPUDataManager *pre_allocated_dm = nullptr,
                                                          hipStream_t stream = nullptr)
 {
-    static_assert(sizeof(KeyT) == 4, "32-bit keys only");
     constexpr bool keys_only = std::is_same<ValueT, gpusort::NullType>::value;
     const bool pairs = !keys_only && dev_values != nullptr;
+    constexpr int VB = keys_only ? 0 : (int)sizeof(ValueT);
+    static_assert(sizeof(KeyT) == 4 || sizeof(KeyT) == 8, "32- or 64-bit keys");
+    static_assert(VB == 0 || VB == 4 || VB == 8, "32- or 64-bit values");
+    if constexpr (sizeof(KeyT) == 8 || VB == 8) {
+        // 64-bit keys and/or values: the wide LSB sort; the result buffer follows from its pass count
+        const int vb = pairs ? VB : 0;
+        const size_t tb = gs_lsb_wide_temp_bytes((uint64_t)key_count, (int)sizeof(KeyT), vb);
+        void *temp = nullptr;
+        void *k2[2] = {dev_keys, dev_sorted_keys_out}, *v2[2] = {dev_values, dev_sorted_values_out};
+        int sel = 0;
+        if (hipMalloc(&temp, tb ? tb : 1) == hipSuccess) {
+            (void)gs_lsb_sort_wide(temp, tb, k2, pairs ? v2 : nullptr, &sel, (uint64_t)key_count, (int)sizeof(KeyT), vb, 0,
+                                   8 * (int)sizeof(KeyT), 0, gpusort::KeyTraits<KeyT>::type, stream);
+            (void)hipStreamSynchronize(stream);
+            (void)hipFree(temp);
+        }
+        return RDXSRT_SortedSequence<KeyT, ValueT>{reinterpret_cast<KeyT *>(k2[sel]),
+                                                   pairs ? reinterpret_cast<ValueT *>(v2[sel]) : nullptr};
+    } else {
     RDXSRT_GPUDataManager *dm = pre_allocated_dm ? pre_allocated_dm : new RDXSRT_GPUDataManager((uint64_t)key_count, pairs);
     uint32_t *sk = nullptr, *sv = nullptr;
     (void)gs_msb_sort_u32(dm->d_temp, dm->bytes, reinterpret_cast<uint32_t *>(dev_keys),
@@ -288,6 +308,7 @@ RDXSRT_SortedSequence<KeyT, ValueT> rdxsrt_unstable_sort(KeyT *dev_keys, ValueT 
                           gpusort::KeyTraits<KeyT>::type, stream, 1);
     if (!pre_allocated_dm) delete dm;
     return RDXSRT_SortedSequence<KeyT, ValueT>{reinterpret_cast<KeyT *>(sk), reinterpret_cast<ValueT *>(sv)};
+    }
 }
 
 // Host-pointer conveniences (gpu_radix_sort.h:511-587): allocate, copy in, sort, copy the

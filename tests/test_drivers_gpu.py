@@ -48,6 +48,20 @@ def test_msb_harness_entropy_sweep():
     assert "[       OK ] Sort_Pairs.UINT_UINT" in text and "FAILED" not in text
 
 
+def test_msb_harness_64bit_cases():
+    """The UINT64 / DOUBLE keys and the 64-bit value combinations of msb/tests (test_sort_keys.cu:154-195,
+    test_sort_pairs.cu:223-281) run through rdxsrt_unstable_sort's wide path."""
+    out = _run(["msb_harness", "-r", "1", "-k", "120000", "-p", "70000", "--gtest_filter=64"])
+    text = "\n".join(out)
+    for name in ("Sort_Keys.Entropy_UINT64", "Sort_Pairs.UINT_UINT64", "Sort_Pairs.UINT64_UINT", "Sort_Pairs.UINT64_UINT64"):
+        assert f"[       OK ] {name}" in text
+    assert "FAILED" not in text and "SKIPPED" not in text
+    out = _run(["msb_harness", "-r", "1", "-k", "120000", "--gtest_filter=DOUBLE"])
+    assert "[       OK ] Sort_Keys.Entropy_DOUBLE" in "\n".join(out)
+    rows = [l for l in out if l.startswith("sort_keys_DOUBLE\t")]
+    assert len(rows) == 12
+
+
 def test_lsb_types_driver_all_type_pairs():
     """Typed DeviceRadixSort driver (32- and 64-bit keys and values) against std::stable_sort."""
     out = _run(["lsb_types", "200003"])
