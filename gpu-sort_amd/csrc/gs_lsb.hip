@@ -811,8 +811,20 @@ int gs_lsb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], uint32
     if (!d_temp || temp_bytes < gs_lsb_temp_bytes(num_items, d_vals != nullptr)) return hipErrorInvalidValue;
     if (!d_keys[0] || !d_keys[1] || (d_vals && (!d_vals[0] || !d_vals[1]))) return hipErrorInvalidValue;
 
-    const LsbWorkspace ws = lsb_carve(d_temp, num_items);
     int sel = *selector;
+    if (num_items <= small_sort_capacity(d_vals != nullptr) && !fused_enabled()) {
+        // fits one workgroup: one launch (CUB's single-tile path); the result lands where the passes would leave it
+        const int passes = (end_bit - begin_bit + RADIX_BITS - 1) / RADIX_BITS, fin = sel ^ (passes & 1);
+        PassParams tw{};
+        lsb_twiddle_masks(key_type, descending, true, true, tw);
+        const int e = small_stable_sort(d_temp, temp_bytes, d_keys[sel], d_keys[fin], d_vals ? d_vals[sel] : nullptr,
+                                        d_vals ? d_vals[fin] : nullptr, (uint32_t)num_items, begin_bit, end_bit, tw.f32_in,
+                                        tw.xor_in, tw.f32_out, tw.xor_out, (hipStream_t)stream);
+        if (e) return e;
+        *selector = fin;
+        return hipSuccess;
+    }
+    const LsbWorkspace ws = lsb_carve(d_temp, num_items);
     const int e = lsb_run_passes(ws, num_items, begin_bit, end_bit, descending, key_type, d_vals != nullptr,
                                  (hipStream_t)stream,
                                  [&](int, int, const uint32_t *&kin, uint32_t *&kout, const uint32_t *&vin, uint32_t *&vout) {
@@ -852,6 +864,12 @@ int gs_lsb_sort_copy_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys
         if (e == hipSuccess && pairs)
             e = hipMemcpyAsync(d_vals_out, d_vals_in, num_items * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
         return (int)e;
+    }
+    if (num_items <= small_sort_capacity(pairs) && !fused_enabled()) {   // one workgroup, straight from IN to OUT
+        PassParams tw{};
+        lsb_twiddle_masks(key_type, descending, true, true, tw);
+        return small_stable_sort(d_temp, temp_bytes, d_keys_in, d_keys_out, d_vals_in, d_vals_out, (uint32_t)num_items, begin_bit,
+                                 end_bit, tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out, s);
     }
     const LsbWorkspace ws = lsb_carve(d_temp, num_items);
     const size_t buf = align256((size_t)num_items * sizeof(uint32_t));

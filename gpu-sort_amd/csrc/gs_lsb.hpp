@@ -63,4 +63,10 @@ int lsb_scan(uint32_t *spine, uint32_t *totals, uint32_t grid, hipStream_t s);
 int lsb_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, const uint32_t *spine,
                   const uint16_t *prefix16, const uint32_t *totals, const PassParams &p, hipStream_t s);
 
+// single-workgroup stable sort of a small array (gs_msb.hip): n <= small_sort_capacity(pairs)
+uint32_t small_sort_capacity(bool pairs);
+int small_stable_sort(void *scratch, size_t scratch_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                      uint32_t n, int begin_bit, int end_bit, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out,
+                      hipStream_t s);
+
 }  // namespace gs

@@ -1015,6 +1015,42 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
     }
 }
 
+// ---- single-workgroup path of the LSB sort (CUB's single-tile path, dispatch_radix_sort.cuh:1182-1187):
+// arrays that fit one workgroup are sorted by ONE stable local sort instead of 3 launches per pass
+__global__ void msb_small_task_kernel(MsbLevel *level, MsbTask *task, uint32_t n, int cls, uint32_t bits, uint32_t shift0)
+{
+    if (threadIdx.x == 0) {
+        MsbLevel z{};
+        z.task_count[cls] = 1;
+        level[0] = z;
+        task[0] = MsbTask{0u, n, bits, shift0};
+    }
+}
+
+uint32_t small_sort_capacity(bool pairs) { return msb_class_cap(msb_num_classes(pairs) - 1); }
+
+int small_stable_sort(void *scratch, size_t scratch_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                      uint32_t n, int begin_bit, int end_bit, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out,
+                      hipStream_t s)
+{
+    const bool pairs = vin != nullptr;
+    if (n == 0 || n > small_sort_capacity(pairs) || scratch_bytes < 256 + sizeof(MsbTask)) return hipErrorInvalidValue;
+    int cls = 0;
+    while (msb_class_cap(cls) < n) ++cls;
+    MsbWs ws{};
+    ws.level = (MsbLevel *)scratch;
+    for (int c = 0; c < MSB_NCLASS; ++c) ws.tasks[c] = (MsbTask *)((char *)scratch + 256);
+    KernelTimer kt(GS_K_MSB_LOCAL_SORT, s);
+    hipLaunchKernelGGL(msb_small_task_kernel, dim3(1), dim3(64), 0, s, ws.level, ws.tasks[cls], n, cls,
+                       (uint32_t)(end_bit - begin_bit), (uint32_t)begin_bit);
+#define GS_SM(C, HV) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV, true>), dim3(1), \
+                                        dim3(msb_class_threads(C)), 0, s, ws, 0, C, kin, kout, vin, vout, f32_in, xor_in, f32_out, xor_out)
+    if (pairs) { if (cls == 0) GS_SM(0, true); else if (cls == 1) GS_SM(1, true); else GS_SM(2, true); }
+    else { if (cls == 0) GS_SM(0, false); else if (cls == 1) GS_SM(1, false); else if (cls == 2) GS_SM(2, false); else GS_SM(3, false); }
+#undef GS_SM
+    return (int)hipGetLastError();
+}
+
 }  // namespace gs
 
 using namespace gs;
