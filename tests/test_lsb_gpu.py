@@ -345,3 +345,30 @@ def test_beyond_2p30_keys(gs, cuda, algo):
     if pairs:
         bad, vsum = gs.check_pairs_enumerated(orig, out_k, out_v)
         assert bad == 0 and vsum == n * (n - 1) // 2
+
+
+@pytest.mark.parametrize("n", [5000, 100003])
+def test_sort_is_capturable_in_a_hip_graph(gs, cuda, oracle, n):
+    """A sort call makes no host-side decisions and no synchronisation, so it can be captured in a HIP
+    graph once and replayed on new data in the same buffers (small path and three-kernel path)."""
+    keys1, keys2 = oracle.gen_uniform(n, seed=1), oracle.gen_zipf(n, seed=2)
+    src = to_dev(keys1, cuda)
+    a, b = src.clone(), torch.empty_like(src)
+    nb = gs.lib.gs_lsb_temp_bytes(n, 0)
+    temp = torch.empty(nb, dtype=torch.uint8, device=cuda)
+    dk = gs.DoubleBuffer(a, b)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        gs.DeviceRadixSort.SortKeys(temp, nb, dk, n, key_type=gs.GS_KEY_U32)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    dk.selector = 0
+    with torch.cuda.graph(g, stream=side):
+        a.copy_(src)
+        gs.DeviceRadixSort.SortKeys(temp, nb, dk, n, key_type=gs.GS_KEY_U32)
+    out = dk.Current()
+    g.replay(); torch.cuda.synchronize()
+    assert np.array_equal(to_u32(out)[:n], np.sort(keys1))
+    src.copy_(to_dev(keys2, cuda))
+    g.replay(); torch.cuda.synchronize()
+    assert np.array_equal(to_u32(out)[:n], np.sort(keys2))
