@@ -85,6 +85,70 @@ __global__ __launch_bounds__(LSB_THREADS) void lsb_upsweep_kernel(const uint32_t
     }
 }
 
+// ---- small arrays (up to LSB_SMALL_TILES tiles): with one wave per tile a handful of waves would each
+// walk 8192 keys in four dependent batches (15 us however small the array).  Here a whole workgroup counts
+// one tile (16 keys per thread, one batch) and leaves the tile's RAW counts in prefix16; the scan kernel
+// below turns them into the chunk-relative prefixes and the spine the downsweep expects.
+constexpr uint32_t LSB_SMALL_TILES = 2048;    // 16 Mi keys
+__global__ __launch_bounds__(LSB_THREADS) void lsb_upsweep_small_kernel(const uint32_t *__restrict__ keys,
+                                                                        uint16_t *__restrict__ prefix16, PassParams p)
+{
+    __shared__ uint32_t hist[LSB_WAVES][RADIX];
+    const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    uint32_t *my = hist[w];
+#pragma unroll
+    for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
+    const uint32_t tile = blockIdx.x;
+    const uint64_t lo = (uint64_t)tile * LSB_TILE;
+    const uint32_t len = (p.n - lo < (uint64_t)LSB_TILE) ? (uint32_t)(p.n - lo) : (uint32_t)LSB_TILE;
+    const uint32_t *src = keys + lo;
+    const uint32_t last = len - 1u;
+    uint32_t v[LSB_KPT];
+#pragma unroll
+    for (int u = 0; u < LSB_KPT; ++u) {
+        const uint32_t idx = (uint32_t)w * (WAVE * LSB_KPT) + u * WAVE + lane;
+        v[u] = src[idx < last ? idx : last];
+    }
+#pragma unroll
+    for (int u = 0; u < LSB_KPT; ++u) {
+        const uint32_t idx = (uint32_t)w * (WAVE * LSB_KPT) + u * WAVE + lane;
+        if (idx < len) hist_add(my, __builtin_amdgcn_ubfe(twiddle_in(v[u], p.f32_in, p.xor_in), p.shift, p.bits));
+    }
+    __syncthreads();
+    if (tid < RADIX) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < LSB_WAVES; ++j) c += hist[j][tid];
+        prefix16[(size_t)tile * RADIX + tid] = (uint16_t)c;        // <= 8192: a full tile of one digit is 0x2000
+    }
+}
+
+// one block per digit, thread c = chunk c (grid <= 256): raw tile counts -> in-chunk exclusive prefixes
+// (in place), chunk totals -> exclusive scan over the chunks (spine row) and the digit total
+__global__ __launch_bounds__(RADIX) void lsb_scan_small_kernel(uint32_t *__restrict__ spine, uint32_t *__restrict__ totals,
+                                                               uint16_t *__restrict__ prefix16, uint32_t grid, uint32_t num_tiles)
+{
+    __shared__ uint32_t scratch[8];
+    const uint32_t d = blockIdx.x, c = threadIdx.x;
+    uint32_t run = 0;
+    if (c < grid) {
+#pragma unroll
+        for (int j = 0; j < LSB_CHUNK; ++j) {
+            const uint32_t t = c * LSB_CHUNK + j;
+            if (t < num_tiles) {
+                uint16_t *q = prefix16 + (size_t)t * RADIX + d;
+                const uint32_t cnt = *q;
+                *q = (uint16_t)run;
+                run += cnt;
+            }
+        }
+    }
+    uint32_t total = 0;
+    const uint32_t ex = block_exclusive_scan_256(run, scratch, &total);
+    if (c < grid) spine[(size_t)d * grid + c] = ex;
+    if (c == 0) totals[d] = total;
+}
+
 // ------------------------------------------------- single-sweep histogram --
 // Digit totals of ALL passes in one read of the keys (single-sweep mode): the digit of
 // pass q is taken from the twiddled key, which is what the later passes see.
@@ -683,8 +747,17 @@ static int lsb_run_passes(const LsbWorkspace &ws, uint64_t num_items, int begin_
         if (!pairs) { vin = nullptr; vout = nullptr; }
         int e;
         if (!fused) {
+            if (p.num_tiles <= LSB_SMALL_TILES) {   // latency-bound sizes: workgroup per tile, chunk prefixes in the scan
+                { KernelTimer kt(GS_K_LSB_UPSWEEP, s);
+                  hipLaunchKernelGGL(lsb_upsweep_small_kernel, dim3(p.num_tiles), dim3(LSB_THREADS), 0, s, kin, ws.prefix16, p); }
+                { KernelTimer kt(GS_K_LSB_SCAN, s);
+                  hipLaunchKernelGGL(lsb_scan_small_kernel, dim3(RADIX), dim3(RADIX), 0, s, ws.spine, ws.totals, ws.prefix16, p.grid,
+                                     p.num_tiles); }
+                if ((e = (int)hipGetLastError())) return e;
+            } else {
             if ((e = lsb_upsweep(kin, ws.spine, ws.prefix16, p, s))) return e;
             if ((e = lsb_scan(ws.spine, ws.totals, p.grid, s))) return e;
+            }
             if ((e = lsb_downsweep(kin, kout, vin, vout, ws.spine, ws.prefix16, ws.totals, p, s))) return e;
             continue;
         }
