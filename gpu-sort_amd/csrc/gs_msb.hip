@@ -643,7 +643,8 @@ struct LocalSmem {
     static constexpr int WAVES = THREADS / WAVE;
     union {
         uint32_t stage[KPT * THREADS * (HAS_VALUES ? 2 : 1)];
-        uint32_t hist[1 << local_b1(KPT * THREADS)];   // first pass: one shared histogram
+        // first pass: one shared histogram of 2^b1 u32 counters, or 2^(b1' + 2) one-byte counters (4 per word)
+        uint32_t hist[1 << (local_b1(KPT * THREADS * (HAS_VALUES ? 2 : 1)) > local_b1(KPT * THREADS) ? local_b1(KPT * THREADS * (HAS_VALUES ? 2 : 1)) : local_b1(KPT * THREADS))];
         uint32_t whist[WAVES][RADIX];        // later passes: wave-private counters
     };
     uint32_t wtot[16];
@@ -659,13 +660,21 @@ struct LocalSmem {
 // stored (their registers are free by then).
 // STABLE (segmented sort): no order-free pass -- every pass is a stable ballot-match pass -- and the task's
 // bits start at bit `pad` (= begin_bit) of the key.
-template <int THREADS, int KPT, bool HAS_VALUES, bool STABLE = false>
+// MODE: LS_ALL = the general pass plan for every task of the list; LS_ONEPASS = only the one-pass byte-counter
+// sort (see below), tasks it cannot take (too many bits, or a bin that reaches 255 keys) are flagged in their
+// `pad` word; LS_FLAGGED = the general plan for the flagged tasks.  The MSB sort launches LS_ONEPASS then
+// LS_FLAGGED per class: two lean kernels instead of one that holds both plans (and spills at 64 VGPRs).
+enum { LS_ALL = 0, LS_ONEPASS = 1, LS_FLAGGED = 2 };
+constexpr uint32_t LS_FLAG = 0x80000000u;
+template <int THREADS, int KPT, bool HAS_VALUES, bool STABLE = false, int MODE = LS_ALL>
 __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_sort_kernel(
     MsbWs ws, int L, int cls, const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k, const uint32_t *__restrict__ src_v,
     uint32_t *__restrict__ dst_v, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out)
 {
     constexpr int WAVES = THREADS / WAVE;
     constexpr int LOCAL_B1 = local_b1(KPT * THREADS);
+    // 2^ONEPASS_BITS byte counters fill (at most) the staging buffer: 13..16 bits
+    constexpr int ONEPASS_BITS = local_b1(KPT * THREADS * (HAS_VALUES ? 2 : 1)) + 2;
     static_assert(KPT * THREADS >= (1 << LOCAL_B1) && KPT * THREADS >= WAVES * RADIX, "counters must fit the staging buffer");
     __shared__ __attribute__((aligned(16))) LocalSmem<THREADS, KPT, HAS_VALUES> sm;
     const uint32_t ntasks = ws.level[L].task_count[cls];
@@ -675,9 +684,23 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
     // every use site takes a fresh, opaque copy of a cheap index base: otherwise the compiler keeps all
     // KPT derived indices and addresses live across the task loop and spills them (64-VGPR budget)
     auto fresh = [](uint32_t x) { asm volatile("" : "+v"(x)); return x; };
-    uint32_t ti = blockIdx.x;
+    static_assert(!(STABLE && MODE != LS_ALL), "the stable sort has one plan");
+    // next task of this workgroup (stride gridDim.x) that this MODE processes; LS_ONEPASS flags the ones it leaves
+    auto advance = [&](uint32_t from, MsbTask &out) {
+        uint32_t t = from;
+        for (; t < ntasks; t += gridDim.x) {
+            const MsbTask c = ws.tasks[cls][t];
+            const bool mine = MODE == LS_ALL ? true
+                              : MODE == LS_ONEPASS ? (c.sort_bits > (uint32_t)LOCAL_B1 && c.sort_bits <= (uint32_t)ONEPASS_BITS)
+                                                   : (c.pad & LS_FLAG) != 0u;
+            if (mine) { out = c; break; }
+            if (MODE == LS_ONEPASS && tid == 0) ws.tasks[cls][t].pad = c.pad | LS_FLAG;
+        }
+        return t;
+    };
+    MsbTask T{};
+    uint32_t ti = advance(blockIdx.x, T);
     if (ti >= ntasks) return;
-    MsbTask T = ws.tasks[cls][ti];
     uint32_t key[KPT], val[HAS_VALUES ? KPT : 1], pos[KPT];
     // unconditional loads from clamped indices (a predicated load waits for its data before the
     // next one is issued: KPT round trips instead of one); padding is applied afterwards
@@ -695,9 +718,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
     };
     request(T);
     for (;;) {
-        const uint32_t tn = ti + gridDim.x;
+        MsbTask Tn = T;
+        const uint32_t tn = advance(ti + gridDim.x, Tn);
         const bool has_next = tn < ntasks;
-        const MsbTask Tn = ws.tasks[cls][has_next ? tn : ti];
         {
             const uint32_t wbase = fresh(wbase0);
 #pragma unroll
@@ -708,6 +731,114 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
             }
         }
         const uint32_t B = T.sort_bits;
+        // ---- (LS_ONEPASS; tasks with more bits than the general plan's first pass takes) one pass on all B bits
+        // when 2^B one-BYTE counters fit the staging buffer (a 16-bit task of the
+        // largest class: 64 KiB): fetch-add on the packed counter word returns the old count of the bin = the
+        // key's rank inside it; then the word is re-read (final counts -> offset inside the word), the words
+        // are summed and scanned, and the word base replaces the counts in place.  A bin that reaches 255 keys
+        // (heavy duplicates) abandons the attempt: the keys are untouched and the general plan below runs.
+        bool done = false;
+        if constexpr (MODE == LS_ONEPASS) {
+            const uint32_t nwords = (1u << B) >> 2, maskB = (1u << B) - 1u;
+            for (uint32_t j = tid; j < nwords; j += THREADS) sm.hist[j] = 0;
+            __syncthreads();
+            uint32_t overflow = 0;
+            {
+                const uint32_t wbase = fresh(wbase0);
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    pos[i] = 0;
+                    if (wbase + i * WAVE < T.size) {
+                        const uint32_t bin = key[i] & maskB, sh = (bin & 3u) * 8u;
+                        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+                        const uint32_t b0 = __builtin_amdgcn_readfirstlane(bin);
+                        uint32_t r;
+                        if (__builtin_amdgcn_ballot_w64(bin == b0) == act) {      // one add for a wave-uniform bin
+                            const uint32_t lower = count_lower_mask(act), cnt = (uint32_t)__popcll(act);
+                            uint32_t old = 0;
+                            if (lower == 0) old = atomicAdd(&sm.hist[b0 >> 2], cnt << sh);
+                            old = (__builtin_amdgcn_readfirstlane(old) >> sh) & 255u;
+                            r = old + lower;
+                            overflow |= (old + cnt > 255u) ? 1u : 0u;
+                        } else {
+                            r = (atomicAdd(&sm.hist[bin >> 2], 1u << sh) >> sh) & 255u;
+                            overflow |= (r >= 255u) ? 1u : 0u;
+                        }
+                        pos[i] = r;
+                    }
+                }
+            }
+            if (!__syncthreads_or((int)overflow)) {
+                {   // offset inside the counter word: keys of the lower bins of the same word
+                    const uint32_t wbase = fresh(wbase0);
+#pragma unroll
+                    for (int i = 0; i < KPT; ++i) {
+                        if (wbase + i * WAVE < T.size) {
+                            const uint32_t bin = key[i] & maskB;
+                            const uint32_t wd = sm.hist[bin >> 2];
+                            pos[i] += __builtin_amdgcn_sad_u8(wd & ((1u << ((bin & 3u) * 8u)) - 1u), 0u, 0u);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]), "+v"(key[i]));
+                __syncthreads();
+                // exclusive scan of the word sums, written over the words (WPT consecutive words per thread)
+                constexpr uint32_t WPT = ((1u << ONEPASS_BITS) >> 2) / THREADS;
+                static_assert(WPT >= 4 && WPT % 4 == 0, "words per thread");
+                const bool act = (uint32_t)tid * WPT < nwords;
+                uint32_t ssum = 0;
+                if (act) {
+#pragma unroll
+                    for (uint32_t q = 0; q < WPT; q += 4) {
+                        const uint4 c4 = reinterpret_cast<const uint4 *>(sm.hist)[((uint32_t)tid * WPT + q) >> 2];
+                        ssum = __builtin_amdgcn_sad_u8(c4.x, 0u, ssum); ssum = __builtin_amdgcn_sad_u8(c4.y, 0u, ssum);
+                        ssum = __builtin_amdgcn_sad_u8(c4.z, 0u, ssum); ssum = __builtin_amdgcn_sad_u8(c4.w, 0u, ssum);
+                    }
+                }
+                const uint32_t inc = wave_inclusive_scan(ssum);
+                if (lane == 63) sm.wtot[w] = inc;
+                __syncthreads();
+                const uint32_t wsv = (lane < WAVES) ? sm.wtot[lane] : 0u;
+                const uint32_t wincl = wave_inclusive_scan(wsv);
+                uint32_t run = (uint32_t)__shfl((int)(wincl - wsv), w, WAVE) + inc - ssum;
+                if (act) {
+#pragma unroll
+                    for (uint32_t q = 0; q < WPT; q += 4) {
+                        uint4 *p4 = reinterpret_cast<uint4 *>(sm.hist) + (((uint32_t)tid * WPT + q) >> 2);
+                        const uint4 c4 = *p4;
+                        uint4 e4;
+                        e4.x = run; run = __builtin_amdgcn_sad_u8(c4.x, 0u, run);
+                        e4.y = run; run = __builtin_amdgcn_sad_u8(c4.y, 0u, run);
+                        e4.z = run; run = __builtin_amdgcn_sad_u8(c4.z, 0u, run);
+                        e4.w = run; run = __builtin_amdgcn_sad_u8(c4.w, 0u, run);
+                        *p4 = e4;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) pos[i] += sm.hist[(key[i] & maskB) >> 2];
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]));
+                __syncthreads();                          // the counters are dead: the buffer takes the keys
+                {
+                    const uint32_t wbase = fresh(wbase0);
+#pragma unroll
+                    for (int i = 0; i < KPT; ++i) {
+                        if (wbase + i * WAVE < T.size) {
+                            if (HAS_VALUES) reinterpret_cast<uint2 *>(sm.stage)[pos[i]] = make_uint2(key[i], val[i]);
+                            else sm.stage[pos[i]] = key[i];
+                        }
+                    }
+                }
+                __syncthreads();
+                done = true;
+            }
+        }
+        if constexpr (MODE == LS_ONEPASS) {
+            if (!done && tid == 0) ws.tasks[cls][ti].pad = T.pad | LS_FLAG;     // a bin overflowed: leave it to LS_FLAGGED
+        } else {
+        done = true;
         const uint32_t b1 = STABLE ? 0u : (B < (uint32_t)LOCAL_B1 ? B : (uint32_t)LOCAL_B1);
         bool in_regs = STABLE;                            // the keys of the first stable pass are still in registers
         if (!STABLE) {   // ---- first pass: shared histogram of 2^b1 bins, order-free ranks
@@ -875,8 +1006,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
             __syncthreads();
             shift += b; rem -= b; --np;
         }
+        }   // general plan
         // ---- request the next task's keys, then store this one from the buffer
         if (has_next) request(Tn);
+        if (done) {
         uint32_t *qk = dst_k + T.offset, *qv = HAS_VALUES ? dst_v + T.offset : nullptr;
         if (HAS_VALUES) {
             for (uint32_t j = tid; j < T.size; j += THREADS) {
@@ -894,6 +1027,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
                 if (j < T.size) *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(qk) + j * 4u) = twiddle_out(pos[i], f32_out, xor_out);
             }
         }
+        }   // done
         __syncthreads();
         if (!has_next) break;
         T = Tn; ti = tn;
@@ -946,19 +1080,36 @@ __global__ void shard_counts_kernel(const uint32_t *__restrict__ row, uint32_t n
 
 // ------------------------------------------------------------------- host --
 
+// `min_bits`: the bits a task of this launch has left (the level's remaining bits, or 8 more for a merged task).
+// The one-pass sort only pays when it replaces TWO passes of the general plan (more bits than the class's first
+// pass takes) and its byte counters fit; a class where neither task kind qualifies goes straight to LS_ALL.
+static inline bool onepass_possible(int min_bits, int b1, int onepass_bits)
+{
+    return (min_bits > b1 && min_bits <= onepass_bits) || (min_bits + 8 > b1 && min_bits + 8 <= onepass_bits);
+}
 template <bool HAS_VALUES, bool STABLE = false>
 static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uint32_t *sk, uint32_t *dk, const uint32_t *sv,
-                               uint32_t *dv, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out, hipStream_t s)
+                               uint32_t *dv, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out, hipStream_t s,
+                               int min_bits = 0)
 {
     KernelTimer kt(GS_K_MSB_LOCAL_SORT, s);
     const uint32_t grid = bound < MSB_MAX_GRID ? bound : MSB_MAX_GRID;   // grid-stride over the task list
-#define GS_LS(C, HV) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV, STABLE>), dim3(grid), \
-                                        dim3(msb_class_threads(C)), 0, s, ws, L, C, sk, dk, sv, dv, f32_in, xor_in, f32_out, xor_out)
+#define GS_LS1(C, HV, M) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV, STABLE, M>), dim3(grid), \
+                                            dim3(msb_class_threads(C)), 0, s, ws, L, C, sk, dk, sv, dv, f32_in, xor_in, f32_out, xor_out)
+    // unstable sort: the one-pass kernel takes what it can and flags the rest for the general one
+#define GS_LS(C, HV)                                                                                                  \
+    do {                                                                                                              \
+        if constexpr (STABLE) { GS_LS1(C, HV, LS_ALL); }                                                              \
+        else if (!onepass_possible(min_bits, local_b1((int)msb_class_cap(C)), local_b1((int)msb_class_cap(C) * (HV ? 2 : 1)) + 2)) \
+            { GS_LS1(C, HV, LS_ALL); }                                                                                \
+        else { GS_LS1(C, HV, LS_ONEPASS); GS_LS1(C, HV, LS_FLAGGED); }                                                \
+    } while (0)
     GS_LS(0, HAS_VALUES);
     GS_LS(1, HAS_VALUES);
     GS_LS(2, HAS_VALUES);
     if (!HAS_VALUES) GS_LS(3, false);
 #undef GS_LS
+#undef GS_LS1
 }
 
 // Levels 1..3 (partition on bytes 2, 1, 0 + the local sorts after each): keys travel between
@@ -1009,8 +1160,8 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
 #undef GS_SC
         }
         if (!last) {
-            if (pairs) launch_local_sorts<true>(ws, L, max_tasks_lvl, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s);
-            else launch_local_sorts<false>(ws, L, max_tasks_lvl, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s);
+            if (pairs) launch_local_sorts<true>(ws, L, max_tasks_lvl, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L);
+            else launch_local_sorts<false>(ws, L, max_tasks_lvl, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L);
         }
     }
 }
@@ -1043,7 +1194,7 @@ int small_stable_sort(void *scratch, size_t scratch_bytes, const uint32_t *kin, 
     KernelTimer kt(GS_K_MSB_LOCAL_SORT, s);
     hipLaunchKernelGGL(msb_small_task_kernel, dim3(1), dim3(64), 0, s, ws.level, ws.tasks[cls], n, cls,
                        (uint32_t)(end_bit - begin_bit), (uint32_t)begin_bit);
-#define GS_SM(C, HV) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV, true>), dim3(1), \
+#define GS_SM(C, HV) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV, true, LS_ALL>), dim3(1), \
                                         dim3(msb_class_threads(C)), 0, s, ws, 0, C, kin, kout, vin, vout, f32_in, xor_in, f32_out, xor_out)
     if (pairs) { if (cls == 0) GS_SM(0, true); else if (cls == 1) GS_SM(1, true); else GS_SM(2, true); }
     else { if (cls == 0) GS_SM(0, false); else if (cls == 1) GS_SM(1, false); else if (cls == 2) GS_SM(2, false); else GS_SM(3, false); }
@@ -1092,8 +1243,8 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
         int cls = 0;
         while (msb_class_cap(cls) < n) ++cls;
         hipLaunchKernelGGL(msb_single_task_kernel, dim3(1), dim3(64), 0, s, ws, n, cls);
-        if (pairs) launch_local_sorts<true>(ws, 0, 1, d_keys, d_keys, d_vals, d_vals, tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out, s);
-        else launch_local_sorts<false>(ws, 0, 1, d_keys, d_keys, nullptr, nullptr, tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out, s);
+        if (pairs) launch_local_sorts<true>(ws, 0, 1, d_keys, d_keys, d_vals, d_vals, tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out, s, 32);
+        else launch_local_sorts<false>(ws, 0, 1, d_keys, d_keys, nullptr, nullptr, tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out, s, 32);
     } else {
         uint32_t *buf_k[2] = {d_keys, d_keys_alt};
         uint32_t *buf_v[2] = {d_vals, d_vals_alt};
@@ -1109,8 +1260,8 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
         // upper bounds of what a level can hold (surplus blocks exit immediately)
         const uint32_t max_tasks_lvl = ws.max_tasks;
         const uint32_t task_grid0 = max_tasks_lvl < 2u * RADIX ? max_tasks_lvl : 2u * RADIX;   // level 0 emits <= 256 tasks
-        if (pairs) launch_local_sorts<true>(ws, 0, task_grid0, d_keys_alt, d_keys, d_vals_alt, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s);
-        else launch_local_sorts<false>(ws, 0, task_grid0, d_keys_alt, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s);
+        if (pairs) launch_local_sorts<true>(ws, 0, task_grid0, d_keys_alt, d_keys, d_vals_alt, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24);
+        else launch_local_sorts<false>(ws, 0, task_grid0, d_keys_alt, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24);
 
         msb_run_levels(ws, num_items, pairs, /*pieces=*/0u, buf_k, buf_v, tw, s);
     }
