@@ -56,7 +56,8 @@ struct MsbTask { uint32_t offset, size, sort_bits, pad; };      // a range to fi
 struct MsbLevel {
     unsigned long long packed;           // hi32: buckets to partition at this level, lo32: their tiles
     uint32_t task_count[MSB_NCLASS];     // local-sort tasks emitted by this level's classification
-    uint32_t pad[2];
+    uint32_t flagged;                    // tasks the one-pass local sort left to the general kernel
+    uint32_t pad;
 };
 
 // A level is partitioned like an LSB pass over its tiles (no atomics, deterministic): the tiles of
@@ -678,6 +679,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
     static_assert(KPT * THREADS >= (1 << LOCAL_B1) && KPT * THREADS >= WAVES * RADIX, "counters must fit the staging buffer");
     __shared__ __attribute__((aligned(16))) LocalSmem<THREADS, KPT, HAS_VALUES> sm;
     const uint32_t ntasks = ws.level[L].task_count[cls];
+    if (MODE == LS_FLAGGED && ws.level[L].flagged == 0u) return;     // nothing was left over (the usual case)
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     uint32_t *my = sm.whist[w];
     const uint32_t wbase0 = (uint32_t)w * (WAVE * KPT) + lane;
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
                               : MODE == LS_ONEPASS ? (c.sort_bits > (uint32_t)LOCAL_B1 && c.sort_bits <= (uint32_t)ONEPASS_BITS)
                                                    : (c.pad & LS_FLAG) != 0u;
             if (mine) { out = c; break; }
-            if (MODE == LS_ONEPASS && tid == 0) ws.tasks[cls][t].pad = c.pad | LS_FLAG;
+            if (MODE == LS_ONEPASS && tid == 0) { ws.tasks[cls][t].pad = c.pad | LS_FLAG; atomicAdd(&ws.level[L].flagged, 1u); }
         }
         return t;
     };
@@ -836,7 +838,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
             }
         }
         if constexpr (MODE == LS_ONEPASS) {
-            if (!done && tid == 0) ws.tasks[cls][ti].pad = T.pad | LS_FLAG;     // a bin overflowed: leave it to LS_FLAGGED
+            if (!done && tid == 0) { ws.tasks[cls][ti].pad = T.pad | LS_FLAG; atomicAdd(&ws.level[L].flagged, 1u); }   // a bin overflowed
         } else {
         done = true;
         const uint32_t b1 = STABLE ? 0u : (B < (uint32_t)LOCAL_B1 ? B : (uint32_t)LOCAL_B1);
@@ -1090,11 +1092,19 @@ static inline bool onepass_possible(int min_bits, int b1, int onepass_bits)
 template <bool HAS_VALUES, bool STABLE = false>
 static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uint32_t *sk, uint32_t *dk, const uint32_t *sv,
                                uint32_t *dv, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out, hipStream_t s,
-                               int min_bits = 0)
+                               int min_bits = 0, uint64_t num_items = 0)
 {
     KernelTimer kt(GS_K_MSB_LOCAL_SORT, s);
-    const uint32_t grid = bound < MSB_MAX_GRID ? bound : MSB_MAX_GRID;   // grid-stride over the task list
-#define GS_LS1(C, HV, M) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV, STABLE, M>), dim3(grid), \
+    // grid-stride over the task list; few blocks suffice for the big classes (empty launches are not free)
+    auto grid_of = [&](int c) {
+        uint64_t b = bound;
+        if (num_items && c > 0) {
+            const uint64_t lim = num_items / msb_class_cap(c - 1) + RADIX;     // a class-c task holds > cap(c-1) keys
+            if (lim < b) b = lim;
+        }
+        return (uint32_t)(b < MSB_MAX_GRID ? (b ? b : 1) : MSB_MAX_GRID);
+    };
+#define GS_LS1(C, HV, M) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV, STABLE, M>), dim3(grid_of(C)), \
                                             dim3(msb_class_threads(C)), 0, s, ws, L, C, sk, dk, sv, dv, f32_in, xor_in, f32_out, xor_out)
     // unstable sort: the one-pass kernel takes what it can and flags the rest for the general one
 #define GS_LS(C, HV)                                                                                                  \
@@ -1160,8 +1170,8 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
 #undef GS_SC
         }
         if (!last) {
-            if (pairs) launch_local_sorts<true>(ws, L, max_tasks_lvl, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L);
-            else launch_local_sorts<false>(ws, L, max_tasks_lvl, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L);
+            if (pairs) launch_local_sorts<true>(ws, L, max_tasks_lvl, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L, num_items);
+            else launch_local_sorts<false>(ws, L, max_tasks_lvl, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L, num_items);
         }
     }
 }
@@ -1260,8 +1270,8 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
         // upper bounds of what a level can hold (surplus blocks exit immediately)
         const uint32_t max_tasks_lvl = ws.max_tasks;
         const uint32_t task_grid0 = max_tasks_lvl < 2u * RADIX ? max_tasks_lvl : 2u * RADIX;   // level 0 emits <= 256 tasks
-        if (pairs) launch_local_sorts<true>(ws, 0, task_grid0, d_keys_alt, d_keys, d_vals_alt, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24);
-        else launch_local_sorts<false>(ws, 0, task_grid0, d_keys_alt, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24);
+        if (pairs) launch_local_sorts<true>(ws, 0, task_grid0, d_keys_alt, d_keys, d_vals_alt, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24, num_items);
+        else launch_local_sorts<false>(ws, 0, task_grid0, d_keys_alt, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24, num_items);
 
         msb_run_levels(ws, num_items, pairs, /*pieces=*/0u, buf_k, buf_v, tw, s);
     }
