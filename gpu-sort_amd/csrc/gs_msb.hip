@@ -209,17 +209,17 @@ __device__ __forceinline__ uint32_t msb_digit(const DigitSel &ds, const uint8_t 
 template <bool REMAP>
 __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int L, const uint32_t *__restrict__ src, DigitSel ds)
 {
-    __shared__ uint32_t lh[MSB_WAVES][RADIX];
+    constexpr int SUB = 4;      // histogram copies per wave, padded rows (see lsb_upsweep_kernel)
+    __shared__ uint32_t lh[MSB_WAVES][SUB][RADIX + 1];
     __shared__ uint8_t tab[REMAP ? (1 << SHARD_MAX_BITS) : 4];
     if (REMAP) load_remap(ds, tab);
     const uint32_t ntiles = (uint32_t)ws.level[L].packed;
     const uint32_t nchunks = ntiles / MSB_WAVES + 1;          // covers tile index `ntiles` too (see classify)
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    uint32_t *my = lh[w];
+    uint32_t *my = lh[w][lane & (SUB - 1)];
     constexpr int BATCH = 32;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-#pragma unroll
-        for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
+        for (int i = lane; i < SUB * (RADIX + 1); i += WAVE) (&lh[w][0][0])[i] = 0;
         const uint32_t g = c * MSB_WAVES + (uint32_t)w;
         if (g < ntiles) {
             const MsbTile T = ws.tiles[g];
@@ -261,7 +261,10 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int 
 #pragma unroll
             for (int j = 0; j < MSB_WAVES; ++j) {
                 ws.prefix16[(size_t)(c * MSB_WAVES + j) * RADIX + tid] = (uint16_t)run;
-                run += lh[j][tid];
+                uint32_t cq = 0;
+#pragma unroll
+                for (int q = 0; q < SUB; ++q) cq += lh[j][q][tid];
+                run += cq;
             }
             ws.spine[(size_t)tid * ws.stride + c] = run;
         }
