@@ -333,6 +333,9 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
     unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
     const unsigned long long t0_ = tprev_, r0_ = __builtin_amdgcn_s_memrealtime();
 #endif
+    // keys only: the waves that issue loads and stores get priority over the ones that rank, so the memory
+    // pipes are fed as early as possible (1.87 -> 1.82 ms; with values it costs 7 %, so pairs keep the default)
+    if (!HAS_VALUES) __builtin_amdgcn_s_setprio(3);
     const uint64_t tile_base = (uint64_t)t * LSB_TILE;
     const uint32_t valid = TAIL ? tail_valid : (uint32_t)LSB_TILE;
 
@@ -356,6 +359,7 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
         }
     }
     GS_PHASE(0);                                   // load issue
+    if (!HAS_VALUES) __builtin_amdgcn_s_setprio(0);
     if (HAS_VALUES) {
         const uint32_t *vin = vals_in + tile_base;
 #pragma unroll
@@ -571,6 +575,7 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
     GS_PHASE(5);                                   // LDS scatter
     __syncthreads();
     GS_PHASE(6);                                   // barrier 3
+    if (!HAS_VALUES) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int i = 0; i < LSB_KPT; ++i) {
         const uint32_t slot = (uint32_t)tid + i * LSB_THREADS;

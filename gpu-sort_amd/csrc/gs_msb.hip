@@ -427,6 +427,7 @@ __device__ __forceinline__ void msb_scatter_tile(ScatterSmem<HAS_VALUES, REMAP> 
     const uint16_t *mybase = sm.wbase[ALLWAVE ? w : 0];
     const uint32_t wbase = (uint32_t)w * (WAVE * MSB_KPT) + lane;
     uint32_t key[MSB_KPT], val[HAS_VALUES ? MSB_KPT : 1], pos[MSB_KPT];
+    if (!HAS_VALUES) __builtin_amdgcn_s_setprio(3);      // loads and stores before ranking (see lsb_downsweep_kernel)
     const uint32_t *pk = src_k + lo, *pv = HAS_VALUES ? src_v + lo : nullptr;   // scalar bases: loads take lane offset + immediate
 #pragma unroll
     for (int i = 0; i < MSB_KPT; ++i) {
@@ -446,6 +447,7 @@ __device__ __forceinline__ void msb_scatter_tile(ScatterSmem<HAS_VALUES, REMAP> 
 #pragma unroll
         for (int i = 0; i < MSB_KPT; ++i) key[i] = twiddle_in(key[i], ds.f32_in, ds.xor_in);
     }
+    if (!HAS_VALUES) __builtin_amdgcn_s_setprio(0);
     // global start of this tile's slice of every sub-bucket (wave 0): cursor + E(tile, d)
     uint32_t tbase[4] = {0, 0, 0, 0};
     if (w == 0) {
@@ -553,6 +555,7 @@ __device__ __forceinline__ void msb_scatter_tile(ScatterSmem<HAS_VALUES, REMAP> 
         }
     }
     __syncthreads();
+    if (!HAS_VALUES) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int i = 0; i < MSB_KPT; ++i) {
         const uint32_t slot = (uint32_t)tid + i * MSB_THREADS;
