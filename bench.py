@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--verify", action="store_true", help="device-side sortedness + checksum on every step")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the bucket-sharded pipeline even on one rank (exercises the N>1 code path)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N>1 rehearsal where every rank uses cuda:0 and the exchange goes over gloo (not a measurement)")
     return ap.parse_args()
 
 
@@ -90,11 +92,16 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import gpu_sort_amd as gs
 
@@ -174,7 +181,7 @@ def main():
     kernels = prof.read()
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -220,7 +227,7 @@ def main():
             "metric": "Gkeys/s sorting 2^30 uint32 keys; achieved HBM GB/s vs roofline",
             "value": round(value, 3), "unit": "Gkeys/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo)" if args.rehearse_on_one_gpu else ""),
             "config": {"workload": (f"{algo}_radix_sort_2^{args.log2n}_u32_{args.dist}_"
                                     f"{'pairs' if args.pairs else 'keys_only'}" + ("_per_gpu_sharded" if sharded_path else "")),
                        "keys_per_gpu": n, "has_values": args.pairs,

@@ -128,6 +128,26 @@ class DeviceOps:
         return check_sorted(keys, count) if count else (0, 0, 0)
 
 
+def _all_to_all(out, inp, recv_counts, send_counts, group):
+    """The one exchange.  RCCL moves device buffers directly; under the gloo backend (CPU tests, or two test
+    ranks sharing one GPU) device buffers are staged through host memory, because gloo has no device all-to-all."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        h_out = torch.empty(out.numel(), dtype=out.dtype)
+        dist.all_to_all_single(h_out, inp.cpu(), recv_counts, send_counts, group=group)
+        out.copy_(h_out)
+        return
+    dist.all_to_all_single(out, inp, recv_counts, send_counts, group=group)
+
+
+def _all_gather(out, inp, group):
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        h = torch.empty(out.numel(), dtype=out.dtype)
+        dist.all_gather_into_tensor(h, inp.cpu(), group=group)
+        out.copy_(h)
+        return
+    dist.all_gather_into_tensor(out, inp, group=group)
+
+
 class ShardedSorter:
     """Sorts a key array that is sharded over the ranks of the default process group."""
 
@@ -169,7 +189,7 @@ class ShardedSorter:
         hist = self.ops.histogram(keys, n, SHARD_BITS)
         if world > 1:
             gathered = torch.empty(world * hist.numel(), dtype=hist.dtype, device=hist.device)
-            dist.all_gather_into_tensor(gathered, hist, group=self.group)
+            _all_gather(gathered, hist, self.group)
             hist_all = gathered.cpu().numpy().reshape(world, -1)
         else:
             hist_all = hist.cpu().numpy().reshape(1, -1)
@@ -180,9 +200,9 @@ class ShardedSorter:
             self._alloc(int(m * 1.1) + 4096)
         self.ops.partition(keys, vals, n, SHARD_BITS, dest, world, self.temp, self.part_k, self.part_v, bin_hist=hist)
         if world > 1:
-            dist.all_to_all_single(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), group=self.group)
+            _all_to_all(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), self.group)
             if self.pairs:
-                dist.all_to_all_single(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), group=self.group)
+                _all_to_all(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), self.group)
             rk, rv = self.recv_k, self.recv_v
         else:
             rk, rv = self.part_k, self.part_v
@@ -196,7 +216,7 @@ class ShardedSorter:
     def _gather_counts(self, counts):
         if self.world > 1:
             gathered = torch.empty(self.world * counts.numel(), dtype=counts.dtype, device=counts.device)
-            dist.all_gather_into_tensor(gathered, counts, group=self.group)
+            _all_gather(gathered, counts, self.group)
             return gathered.cpu().numpy().reshape(self.world, -1)
         return counts.cpu().numpy().reshape(1, -1)
 
@@ -216,9 +236,9 @@ class ShardedSorter:
             self._alloc(int(m * 1.1) + 4096)
         if world > 1:
             # bucket order = key order and dest is monotone: rank r's share is one contiguous slice of part_k
-            dist.all_to_all_single(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), group=self.group)
+            _all_to_all(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), self.group)
             if self.pairs:
-                dist.all_to_all_single(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), group=self.group)
+                _all_to_all(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), self.group)
             rk, rv = self.recv_k, self.recv_v
         else:
             rk, rv = self.part_k, self.part_v

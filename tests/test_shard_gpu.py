@@ -148,3 +148,57 @@ def test_finish_rejects_inconsistent_piece_table(gs, cuda):
     pieces = np.zeros((2, 256), np.uint64); pieces[0, 3] = 400; pieces[1, 3] = 500     # 900 != 1000
     with pytest.raises(gs.GpuSortError):
         ops.finish(ops.empty(1000), None, 1000, ops.empty(1000), None, pieces, temp)
+
+
+def _gpu_rank_worker(rank, world, port, n, dist_kind, pairs, pipeline, out_dir):
+    """One rank of a multi-rank sort whose compute runs on the (shared) GPU through the real DeviceOps; the
+    exchange goes over gloo (device buffers staged through the host: RCCL needs one GPU per rank)."""
+    import os, sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gpu_sort_amd as gs
+    from gpu_sort_amd import sharded
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    gen = gs.generate_uniform_keys if dist_kind == "uniform" else gs.generate_zipf_keys
+    keys = gen(n, seed=0, start=rank * n, device=dev)
+    vals = gs.generate_enumerated_values(n, start=rank * n, device=dev) if pairs else None
+    srt = sharded.ShardedSorter(n, pairs, dev, pipeline=pipeline, local_algo="lsb")
+    chk = srt.input_checksum(keys)
+    sk, sv, cnt = srt.sort(keys, vals)
+    torch.cuda.synchronize()
+    ok, _ = srt.verify(sk, cnt, chk)
+    assert ok, "sharded result fails the global properties"
+    np.save(os.path.join(out_dir, f"k{rank}.npy"), sk[:cnt].cpu().numpy().view(np.uint32))
+    if pairs:
+        np.save(os.path.join(out_dir, f"v{rank}.npy"), sv[:cnt].cpu().numpy().view(np.uint32))
+    with open(os.path.join(out_dir, f"p{rank}.txt"), "w") as f:
+        f.write(srt.last["pipeline"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dist_kind,pairs,pipeline", [(2, "uniform", False, "msb"), (4, "uniform", True, "msb"),
+                                                            (3, "zipf", False, "msb"), (2, "uniform", True, "partition")])
+def test_multi_rank_on_one_gpu_over_gloo(tmp_path, cuda, oracle, world, dist_kind, pairs, pipeline):
+    """world ranks (processes) share this GPU: the real kernels run for every rank, with pieces arriving from
+    every other rank; only the transport differs from the 8-GPU run (gloo + host staging instead of RCCL)."""
+    import socket
+    import torch.multiprocessing as mp
+    n = 400003
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gpu_rank_worker, args=(world, port, n, dist_kind, pairs, pipeline, str(tmp_path)), nprocs=world, join=True)
+    gen = {"uniform": oracle.gen_uniform, "zipf": oracle.gen_zipf}[dist_kind]
+    all_keys = np.concatenate([gen(n, 0, r * n) for r in range(world)])
+    got = np.concatenate([np.load(tmp_path / f"k{r}.npy") for r in range(world)])
+    assert np.array_equal(got, np.sort(all_keys))
+    if pairs:
+        gv = np.concatenate([np.load(tmp_path / f"v{r}.npy") for r in range(world)])
+        assert oracle.msb_check_pairs_enumerated(all_keys, got, gv) == 0
+    assert {open(tmp_path / f"p{r}.txt").read() for r in range(world)} == {pipeline}
