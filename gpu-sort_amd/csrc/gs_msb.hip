@@ -56,7 +56,8 @@ struct MsbTask { uint32_t offset, size, sort_bits, pad; };      // a range to fi
 struct MsbLevel {
     unsigned long long packed;           // hi32: buckets to partition at this level, lo32: their tiles
     uint32_t task_count[MSB_NCLASS];     // local-sort tasks emitted by this level's classification
-    uint32_t flagged;                    // tasks the one-pass local sort left to the general kernel
+    uint32_t flagged;                    // != 0: the one-pass local sort left tasks to the general kernel (a plain store:
+                                         // thousands of atomics on one word would cost a millisecond)
     uint32_t pad;
 };
 
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int 
                 for (int j = 0; j < MSB_TILE / WAVE; j += BATCH) {
                     uint32_t v[BATCH];
 #pragma unroll
-                    for (int u = 0; u < BATCH; ++u) v[u] = p[(j + u) * WAVE + lane];
+                    for (int u = 0; u < BATCH; ++u) v[u] = __builtin_nontemporal_load(&p[(j + u) * WAVE + lane]);
 #pragma unroll
                     for (int u = 0; u < BATCH; ++u) count(v[u]);
                 }
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int 
 #pragma unroll
                     for (int u = 0; u < BATCH; ++u) {
                         const uint32_t idx = j + u * WAVE + lane;
-                        v[u] = p[idx < last ? idx : last];
+                        v[u] = __builtin_nontemporal_load(&p[idx < last ? idx : last]);
                     }
 #pragma unroll
                     for (int u = 0; u < BATCH; ++u)
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
                               : MODE == LS_ONEPASS ? (c.sort_bits > (uint32_t)LOCAL_B1 && c.sort_bits <= (uint32_t)ONEPASS_BITS)
                                                    : (c.pad & LS_FLAG) != 0u;
             if (mine) { out = c; break; }
-            if (MODE == LS_ONEPASS && tid == 0) { ws.tasks[cls][t].pad = c.pad | LS_FLAG; atomicAdd(&ws.level[L].flagged, 1u); }
+            if (MODE == LS_ONEPASS && tid == 0) { ws.tasks[cls][t].pad = c.pad | LS_FLAG; ws.level[L].flagged = 1u; }
         }
         return t;
     };
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
             }
         }
         if constexpr (MODE == LS_ONEPASS) {
-            if (!done && tid == 0) { ws.tasks[cls][ti].pad = T.pad | LS_FLAG; atomicAdd(&ws.level[L].flagged, 1u); }   // a bin overflowed
+            if (!done && tid == 0) { ws.tasks[cls][ti].pad = T.pad | LS_FLAG; ws.level[L].flagged = 1u; }   // a bin overflowed
         } else {
         done = true;
         const uint32_t b1 = STABLE ? 0u : (B < (uint32_t)LOCAL_B1 ? B : (uint32_t)LOCAL_B1);

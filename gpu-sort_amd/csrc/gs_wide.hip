@@ -73,7 +73,7 @@ __global__ __launch_bounds__(W_THREADS) void wide_upsweep_kernel(const K *__rest
 #pragma unroll
             for (int u = 0; u < GB; ++u) {
                 const uint32_t idx = j + u * WAVE + lane;
-                v[u] = src[idx < last ? idx : last];
+                v[u] = __builtin_nontemporal_load(&src[idx < last ? idx : last]);
             }
 #pragma unroll
             for (int u = 0; u < GB; ++u)

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Builds gpu-sort_amd/lib/libgpusort_<name>.so from the current sources with extra -D flags, in its own
+# object directory (for tools/ab.sh):  tools/build_variant.sh <name> "<flags>"
+name="$1"; flags="$2"
+cd "$(dirname "$0")/../gpu-sort_amd/csrc" || exit 1
+obj=/tmp/gs_variant_$name; mkdir -p $obj
+for f in *.hip; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wno-unused-result -Wno-unused-value $flags -c $f -o $obj/${f%.hip}.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libgpusort_$name.so $obj/*.o && echo built libgpusort_$name.so

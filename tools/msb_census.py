@@ -24,4 +24,4 @@ print({k: round(v[0], 3) for k, v in prof.read().items()})
 for L in range(4):
     packed, t0, t1, t2, t3, flagged, _ = struct.unpack_from("<Q6I", raw, L * 32)
     print(f"level {L}: buckets {packed >> 32:7d}  tiles {packed & 0xffffffff:8d} ({(packed & 0xffffffff) * 8192 / n:6.1%} of the keys)  "
-          f"tasks per class {[t0, t1, t2, t3]}  flagged {flagged}")
+          f"tasks per class {[t0, t1, t2, t3]}  tasks left to the general plan: {"yes" if flagged else "no"}")
