@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=27)
     ap.add_argument("--verify", action="store_true", help="device-side sortedness + checksum on every step")
+    ap.add_argument("--exchange-groups", type=int, default=4,
+                    help="N>1: collectives the all-to-all is cut into (group g is finished while g+1.. are in flight)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the bucket-sharded pipeline even on one rank (exercises the N>1 code path)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -124,7 +126,7 @@ def main():
         from gpu_sort_amd import sharded
         # default: exchange after the first MSB digit pass; --algo lsb|msb: group-by-destination + full local sort
         runner = sharded.ShardedSorter(n, args.pairs, dev, local_algo=args.algo or "lsb",
-                                       pipeline="partition" if args.algo else "msb")
+                                       pipeline="partition" if args.algo else "msb", groups=args.exchange_groups)
         nbytes = 0
         temp = None
     elif algo == "lsb":
@@ -185,6 +187,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # outside the timed region: one more sharded sort with a host synchronisation after every stage and the
+    # exchange as ONE collective, so that the exchange time is broken out (max over ranks)
+    stages = None
+    groups_used = runner.last.get("groups") if sharded_path and runner.last else None
+    if sharded_path and not args.algo:
+        runner.stage_times = {}
+        runner.sort(inputs[-1], vals[-1] if args.pairs else None)
+        st, runner.stage_times = runner.stage_times, None
+        if st:
+            names = ["first_pass_ms", "exchange_ms", "finish_ms"]
+            t = torch.tensor([st[k] for k in names], dtype=torch.float64, device="cpu" if (args.rehearse_on_one_gpu or world == 1) else dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            stages = {k: round(float(v), 3) for k, v in zip(names, t.tolist())}
+
     verified = None
     if args.verify and not sharded_path:
         verified = True
@@ -221,7 +238,7 @@ def main():
                      "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
                      "logical_GBps_cub_style": round(8 * n / (ms_per_step * 1e-3) / 1e9, 1)}
         cpu = None
-        if not args.no_cpu_baseline and world >= 1:
+        if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(min(args.cpu_sample_log2, args.log2n), args.pairs)
         line = {
             "metric": "Gkeys/s sorting 2^30 uint32 keys; achieved HBM GB/s vs roofline",
@@ -231,9 +248,11 @@ def main():
             "config": {"workload": (f"{algo}_radix_sort_2^{args.log2n}_u32_{args.dist}_"
                                     f"{'pairs' if args.pairs else 'keys_only'}" + ("_per_gpu_sharded" if sharded_path else "")),
                        "keys_per_gpu": n, "has_values": args.pairs,
+                       **({"exchange_groups": groups_used} if sharded_path else {}),
                        "algorithm": ((f"shard_partition+local_{args.algo}" if args.algo else "msb_first_pass+all_to_all+msb_finish")
                                      if sharded_path else algo),
                        "distribution": args.dist, "parallelism": "single" if not sharded_path else f"msb_bucket_shard{world}"},
+            "stages_ms_serialised": stages,
             "roofline": roofline, "whole_sort": whole, "cpu_baseline": cpu,
             "kernels_ms_total": {k: [round(v[0], 3), v[1]] for k, v in kernels.items()},
         }

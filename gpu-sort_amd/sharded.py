@@ -7,9 +7,13 @@ cut at its first digit ("msb" pipeline, the default):
   2. all ranks exchange the bucket sizes (all_gather, 2 KiB)            (torch.distributed)
   3. every rank computes the same monotone bucket -> rank map with balanced totals; a rank's
      share is then ONE contiguous slice of every grouped shard
-  4. one all_to_all_single with uneven splits moves every top-level bucket to its owner
+  4. one all-to-all with uneven splits moves every top-level bucket to its owner.  It is issued as
+     `groups` collectives, each carrying one run of the owner's buckets (about 1/groups of its keys),
+     all enqueued at once on RCCL's stream
   5. every rank finishes the MSB sort on the buckets it received, picking the pieces up where
      they lie (no regrouping pass)                                      (gs_msb_finish_u32)
+     -- group g is finished on the compute stream as soon as its collective is done, while the
+     collectives of groups g+1.. are still moving data over xGMI
 Rank r then holds the r-th slice of the globally sorted sequence.
 
 When 256 buckets cannot balance the ranks (a heavy top byte), the "partition" pipeline is used
@@ -45,6 +49,28 @@ def compute_splits(hist_all, world):
         dest = np.maximum.accumulate(dest)          # monotone by construction; keep it so under rounding
     per_rank = np.array([int(tot[dest == r].sum()) for r in range(world)], dtype=np.int64)
     return dest, per_rank
+
+
+def group_bins(hist_all, dest, world, groups):
+    """group_of_bin: every rank's run of bins cut into `groups` runs of about equal key totals (monotone
+    inside a rank, so a (rank, group) pair is again one contiguous run of bins).  A function of the gathered
+    sizes only: every rank computes the same map."""
+    tot = hist_all.sum(axis=0).astype(np.float64)
+    grp = np.zeros(tot.size, np.int64)
+    if groups <= 1:
+        return grp
+    for r in range(world):
+        sel = np.nonzero(dest == r)[0]
+        if sel.size == 0:
+            continue
+        t = tot[sel]
+        total = t.sum()
+        if total == 0:
+            continue
+        before = np.cumsum(t) - t
+        g = np.minimum((before * groups / total).astype(np.int64), groups - 1)
+        grp[sel] = np.maximum.accumulate(g)
+    return grp
 
 
 def exchange_plan(hist_all, dest, rank, world):
@@ -148,16 +174,33 @@ def _all_gather(out, inp, group):
     dist.all_gather_into_tensor(out, inp, group=group)
 
 
+def _all_to_all_lists(outs, ins, group):
+    """All-to-all of per-peer tensors (views into the grouped shard / the receive buffer).  RCCL: asynchronous on
+    its own stream, returns the work handle.  gloo: one all_to_all_single of host copies, returns None."""
+    if dist.get_backend(group) == "gloo":
+        h_in = torch.cat([t.cpu() for t in ins])
+        h_out = torch.empty(sum(o.numel() for o in outs), dtype=h_in.dtype)
+        dist.all_to_all_single(h_out, h_in, [o.numel() for o in outs], [t.numel() for t in ins], group=group)
+        pos = 0
+        for o in outs:
+            o.copy_(h_out[pos:pos + o.numel()])
+            pos += o.numel()
+        return None
+    return dist.all_to_all(outs, ins, group=group, async_op=True)
+
+
 class ShardedSorter:
     """Sorts a key array that is sharded over the ranks of the default process group."""
 
     def __init__(self, keys_per_rank, pairs, device, ops=None, local_algo="lsb", slack=1.25, group=None, pipeline="msb",
-                 max_imbalance=1.2):
+                 max_imbalance=1.2, groups=4):
         """pipeline: "msb" (exchange after the first digit pass, falls back when 256 buckets leave a rank with
         more than max_imbalance x its fair share) or "partition" (12-bit group-by-destination + full local sort,
-        local_algo = "lsb" | "msb")."""
+        local_algo = "lsb" | "msb").  groups: collectives the exchange of the "msb" pipeline is cut into (the
+        finish of one group overlaps the transfer of the next; 1 = one collective, no overlap)."""
         self.n, self.pairs, self.device, self.group = keys_per_rank, pairs, device, group
-        self.pipeline, self.max_imbalance = pipeline, max_imbalance
+        self.pipeline, self.max_imbalance, self.groups = pipeline, max_imbalance, max(1, int(groups))
+        self.stage_times = None        # set to {} to get host-synchronised stage times of the next "msb" sort
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.ops = ops if ops is not None else DeviceOps(device)
@@ -224,6 +267,11 @@ class ShardedSorter:
         """Exchange after the first digit pass.  Returns None when top-byte buckets cannot balance the ranks
         (every rank takes the same decision: it is a function of the gathered sizes only)."""
         n, world, rank = self.n, self.world, self.rank
+        timed = self.stage_times is not None
+        if timed:
+            import time
+            self._sync()
+            t0 = time.perf_counter()
         counts = self.ops.first_pass(keys, vals, n, self.temp, self.part_k, self.part_v)
         hist_all = self._gather_counts(counts)                       # (world, 256)
         dest, per_rank = compute_splits(hist_all, world)
@@ -234,18 +282,74 @@ class ShardedSorter:
         m = int(recv.sum())
         if m > self.cap:
             self._alloc(int(m * 1.1) + 4096)
-        if world > 1:
-            # bucket order = key order and dest is monotone: rank r's share is one contiguous slice of part_k
-            _all_to_all(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), self.group)
+        if timed:
+            self._sync()
+            t1 = time.perf_counter()
+        if world == 1:
+            pieces = np.where(dest[None, :] == rank, hist_all, 0)
+            self.ops.finish(self.part_k, self.part_v, m, self.alt_k, self.alt_v, pieces, self.temp)
+            if timed:
+                self._sync()
+                self.stage_times.update(first_pass_ms=(t1 - t0) * 1e3, exchange_ms=0.0, finish_ms=(time.perf_counter() - t1) * 1e3)
+            self.last = dict(count=m, send=send, recv=recv, per_rank=per_rank, dest=dest, pipeline="msb", groups=1)
+            return self.alt_k, self.alt_v, m
+        # bucket order = key order, dest and grp are monotone: what goes to (rank r, group g) is one contiguous
+        # slice of the grouped shard.  The receive buffer is group-major, source-major inside a group.
+        G = 1 if timed else self.groups
+        grp = group_bins(hist_all, dest, world, G)
+        mine = hist_all[rank].astype(np.int64)
+        my_off = np.cumsum(mine) - mine
+        own = [(dest == rank) & (grp == g) for g in range(G)]
+        recv_g = [np.array([int(hist_all[s][own[g]].sum()) for s in range(world)], dtype=np.int64) for g in range(G)]
+        m_g = [int(x.sum()) for x in recv_g]
+        goff = np.concatenate(([0], np.cumsum(m_g))).astype(np.int64)
+        works = []
+        for g in range(G):
+            ins_k, outs_k, ins_v, outs_v = [], [], [], []
+            o = int(goff[g])
+            for r in range(world):
+                sel = np.nonzero((dest == r) & (grp == g))[0]
+                start = int(my_off[sel[0]]) if sel.size else 0
+                cnt = int(mine[sel].sum()) if sel.size else 0
+                c = int(recv_g[g][r])
+                ins_k.append(self.part_k[start:start + cnt])
+                outs_k.append(self.recv_k[o:o + c])
+                if self.pairs:
+                    ins_v.append(self.part_v[start:start + cnt])
+                    outs_v.append(self.recv_v[o:o + c])
+                o += c
+            w = [_all_to_all_lists(outs_k, ins_k, self.group)]
             if self.pairs:
-                _all_to_all(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), self.group)
-            rk, rv = self.recv_k, self.recv_v
-        else:
-            rk, rv = self.part_k, self.part_v
-        pieces = np.where(dest[None, :] == rank, hist_all, 0)       # what every source sent me, per top byte
-        sk, sv = self.ops.finish(rk, rv, m, self.alt_k, self.alt_v, pieces, self.temp)
-        self.last = dict(count=m, send=send, recv=recv, per_rank=per_rank, dest=dest, pipeline="msb")
-        return sk, sv, m
+                w.append(_all_to_all_lists(outs_v, ins_v, self.group))
+            works.append(w)
+        if timed:
+            for w in works:
+                for h in w:
+                    if h is not None:
+                        h.wait()
+            self._sync()
+            t2 = time.perf_counter()
+        for g in range(G):
+            for h in works[g]:
+                if h is not None:
+                    h.wait()                      # the compute stream waits; the host does not
+            if m_g[g] == 0:
+                continue
+            o = int(goff[g])
+            pieces = np.where(own[g][None, :], hist_all, 0)     # what every source sent me in this group, per top byte
+            self.ops.finish(self.recv_k[o:], self.recv_v[o:] if self.pairs else None, m_g[g], self.alt_k[o:],
+                            self.alt_v[o:] if self.pairs else None, pieces, self.temp)
+        if timed:
+            self._sync()
+            self.stage_times.update(first_pass_ms=(t1 - t0) * 1e3, exchange_ms=(t2 - t1) * 1e3,
+                                    finish_ms=(time.perf_counter() - t2) * 1e3)
+        self.last = dict(count=m, send=send, recv=recv, per_rank=per_rank, dest=dest, pipeline="msb", groups=G,
+                         group_counts=m_g)
+        return self.alt_k, self.alt_v, m
+
+    def _sync(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
 
     def verify(self, sorted_keys, count, input_checksum=None):
         """Global correctness from size-independent properties: every rank's slice is sorted, slices are

@@ -150,7 +150,7 @@ def test_finish_rejects_inconsistent_piece_table(gs, cuda):
         ops.finish(ops.empty(1000), None, 1000, ops.empty(1000), None, pieces, temp)
 
 
-def _gpu_rank_worker(rank, world, port, n, dist_kind, pairs, pipeline, out_dir):
+def _gpu_rank_worker(rank, world, port, n, dist_kind, pairs, pipeline, out_dir, groups=4):
     """One rank of a multi-rank sort whose compute runs on the (shared) GPU through the real DeviceOps; the
     exchange goes over gloo (device buffers staged through the host: RCCL needs one GPU per rank)."""
     import os, sys
@@ -167,10 +167,16 @@ def _gpu_rank_worker(rank, world, port, n, dist_kind, pairs, pipeline, out_dir):
     gen = gs.generate_uniform_keys if dist_kind == "uniform" else gs.generate_zipf_keys
     keys = gen(n, seed=0, start=rank * n, device=dev)
     vals = gs.generate_enumerated_values(n, start=rank * n, device=dev) if pairs else None
-    srt = sharded.ShardedSorter(n, pairs, dev, pipeline=pipeline, local_algo="lsb")
+    srt = sharded.ShardedSorter(n, pairs, dev, pipeline=pipeline, local_algo="lsb", groups=groups)
     chk = srt.input_checksum(keys)
+    if groups == 1 and pipeline == "msb":
+        srt.stage_times = {}                 # the serialised, timed variant bench.py uses for its stage breakdown
     sk, sv, cnt = srt.sort(keys, vals)
     torch.cuda.synchronize()
+    if groups == 1 and pipeline == "msb":
+        assert set(srt.stage_times) == {"first_pass_ms", "exchange_ms", "finish_ms"}
+    if pipeline == "msb":
+        assert srt.last["groups"] == groups and sum(srt.last["group_counts"]) == cnt
     ok, _ = srt.verify(sk, cnt, chk)
     assert ok, "sharded result fails the global properties"
     np.save(os.path.join(out_dir, f"k{rank}.npy"), sk[:cnt].cpu().numpy().view(np.uint32))
@@ -182,9 +188,10 @@ def _gpu_rank_worker(rank, world, port, n, dist_kind, pairs, pipeline, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dist_kind,pairs,pipeline", [(2, "uniform", False, "msb"), (4, "uniform", True, "msb"),
-                                                            (3, "zipf", False, "msb"), (2, "uniform", True, "partition")])
-def test_multi_rank_on_one_gpu_over_gloo(tmp_path, cuda, oracle, world, dist_kind, pairs, pipeline):
+@pytest.mark.parametrize("world,dist_kind,pairs,pipeline,groups",
+                         [(2, "uniform", False, "msb", 4), (4, "uniform", True, "msb", 3), (3, "zipf", False, "msb", 4),
+                          (2, "uniform", True, "msb", 1), (2, "uniform", True, "partition", 4)])
+def test_multi_rank_on_one_gpu_over_gloo(tmp_path, cuda, oracle, world, dist_kind, pairs, pipeline, groups):
     """world ranks (processes) share this GPU: the real kernels run for every rank, with pieces arriving from
     every other rank; only the transport differs from the 8-GPU run (gloo + host staging instead of RCCL)."""
     import socket
@@ -193,7 +200,8 @@ def test_multi_rank_on_one_gpu_over_gloo(tmp_path, cuda, oracle, world, dist_kin
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_gpu_rank_worker, args=(world, port, n, dist_kind, pairs, pipeline, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_gpu_rank_worker, args=(world, port, n, dist_kind, pairs, pipeline, str(tmp_path), groups), nprocs=world,
+             join=True)
     gen = {"uniform": oracle.gen_uniform, "zipf": oracle.gen_zipf}[dist_kind]
     all_keys = np.concatenate([gen(n, 0, r * n) for r in range(world)])
     got = np.concatenate([np.load(tmp_path / f"k{r}.npy") for r in range(world)])

@@ -86,7 +86,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, dist_kind, pairs, out_dir, pipeline="msb"):
+def _worker(rank, world, port, n, dist_kind, pairs, out_dir, pipeline="msb", groups=4):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -96,7 +96,7 @@ def _worker(rank, world, port, n, dist_kind, pairs, out_dir, pipeline="msb"):
     gen = {"uniform": O.gen_uniform, "zipf": O.gen_zipf}[dist_kind]
     keys = gen(n, 0, rank * n) if dist_kind != "const" else np.full(n, 7, np.uint32)
     vals = (O.gen_enumerated(n, rank * n)) if pairs else None
-    srt = sharded.ShardedSorter(n, pairs, torch.device("cpu"), ops=NumpyOps(), pipeline=pipeline)
+    srt = sharded.ShardedSorter(n, pairs, torch.device("cpu"), ops=NumpyOps(), pipeline=pipeline, groups=groups)
     tk = torch.from_numpy(keys.view(np.int32).copy())
     tv = torch.from_numpy(vals.view(np.int32).copy()) if pairs else None
     chk = srt.input_checksum(tk)
@@ -104,6 +104,8 @@ def _worker(rank, world, port, n, dist_kind, pairs, out_dir, pipeline="msb"):
     ok, glob = srt.verify(sk, cnt, chk)
     assert ok, "sharded result fails the global properties"
     assert int(srt.last["send"].sum()) == n and int(srt.last["recv"].sum()) == cnt
+    if srt.last["pipeline"] == "msb" and world > 1:
+        assert srt.last["groups"] == groups and sum(srt.last["group_counts"]) == cnt
     with open(os.path.join(out_dir, f"p{rank}.txt"), "w") as f:
         f.write(srt.last["pipeline"])
     np.save(os.path.join(out_dir, f"k{rank}.npy"), sk[:cnt].numpy().view(np.uint32))
@@ -113,12 +115,14 @@ def _worker(rank, world, port, n, dist_kind, pairs, out_dir, pipeline="msb"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dist_kind,pairs,pipeline", [(2, "uniform", False, "msb"), (2, "zipf", True, "msb"),
-                                                            (4, "uniform", True, "msb"), (2, "uniform", True, "partition"),
-                                                            (4, "zipf", False, "partition")])
-def test_sharded_sort_over_gloo(tmp_path, oracle, world, dist_kind, pairs, pipeline):
+@pytest.mark.parametrize("world,dist_kind,pairs,pipeline,groups",
+                         [(2, "uniform", False, "msb", 4), (2, "zipf", True, "msb", 4), (4, "uniform", True, "msb", 3),
+                          (3, "uniform", False, "msb", 1), (2, "uniform", True, "msb", 200),     # more groups than buckets
+                          (2, "uniform", True, "partition", 4), (4, "zipf", False, "partition", 4)])
+def test_sharded_sort_over_gloo(tmp_path, oracle, world, dist_kind, pairs, pipeline, groups):
     n = 50000
-    mp.spawn(_worker, args=(world, _free_port(), n, dist_kind, pairs, str(tmp_path), pipeline), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, dist_kind, pairs, str(tmp_path), pipeline, groups), nprocs=world,
+             join=True)
     used = {open(tmp_path / f"p{r}.txt").read() for r in range(world)}
     assert len(used) == 1                                             # every rank took the same pipeline
     if dist_kind == "uniform":
@@ -133,6 +137,29 @@ def test_sharded_sort_over_gloo(tmp_path, oracle, world, dist_kind, pairs, pipel
     sizes = [np.load(tmp_path / f"k{r}.npy").size for r in range(world)]
     if dist_kind == "uniform":
         assert max(sizes) < 1.1 * n                                   # balanced to within a few bins
+
+
+def test_group_bins_properties():
+    """Every rank's run of bins is cut into monotone groups of about equal totals; all keys are covered once."""
+    sys.path.insert(0, ROOT)
+    from gpu_sort_amd.sharded import compute_splits, group_bins
+    rng = np.random.default_rng(1)
+    for world in (2, 3, 8):
+        hist = rng.integers(0, 1000, size=(world, 256)).astype(np.int64)
+        hist[:, 17] = 0                                               # an empty bucket
+        dest, per_rank = compute_splits(hist, world)
+        for groups in (1, 2, 4, 300):
+            grp = group_bins(hist, dest, world, groups)
+            assert grp.min() >= 0 and grp.max() < groups
+            tot = hist.sum(axis=0)
+            for r in range(world):
+                sel = dest == r
+                assert np.all(np.diff(grp[sel]) >= 0)                 # contiguous runs of bins per (rank, group)
+                per_group = np.array([tot[sel & (grp == g)].sum() for g in range(groups)])
+                assert per_group.sum() == per_rank[r]
+                if groups <= 4:
+                    assert per_group.max() <= per_rank[r] / groups + tot[sel].max()   # balanced to within one bucket
+    assert np.all(group_bins(np.zeros((2, 256), np.int64), np.zeros(256, np.uint8), 2, 4) == 0)    # empty input
 
 
 def test_compute_splits_properties():
