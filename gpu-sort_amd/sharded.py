@@ -318,7 +318,22 @@ class ShardedSorter:
                     ins_v.append(self.part_v[start:start + cnt])
                     outs_v.append(self.recv_v[o:o + c])
                 o += c
-            w = [_all_to_all_lists(outs_k, ins_k, self.group)]
+            if G == 1:
+                # one collective: the slices are adjacent in rank order, so the plain all_to_all_single does it
+                _all_to_all(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), self.group)
+                if self.pairs:
+                    _all_to_all(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), self.group)
+                works.append([])
+                break
+            try:
+                w = [_all_to_all_lists(outs_k, ins_k, self.group)]
+            except (RuntimeError, NotImplementedError):
+                if g != 0:
+                    raise
+                # a backend without the list form of all_to_all (argument checking fails before anything is
+                # enqueued, and on every rank alike): one collective from now on
+                self.groups = 1
+                return self._sort_msb(keys, vals)
             if self.pairs:
                 w.append(_all_to_all_lists(outs_v, ins_v, self.group))
             works.append(w)
