@@ -28,6 +28,7 @@
 //   - ranking inside the local sort is the wave64 ballot/popcount match of the
 //     LSB path; the scatter of an unstable partition ranks with LDS atomics.
 #include "gs_device.hpp"
+#include <new>
 #include "gs_lsb.hpp"
 #include <type_traits>
 #include <cstdlib>
@@ -1382,38 +1383,53 @@ int gs_msb_finish_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_
     const uint32_t extra = (uint32_t)num_src * RADIX;
     const MsbWs ws = msb_carve((char *)d_temp + align256(lsb_temp_bytes(num_items)), num_items, pairs, extra);
 
-    // host side of what the level-0 classification does on one GPU: bucket list + pieces of level 1
-    MsbBucket hb[RADIX];
-    MsbPiece *hp = new MsbPiece[(size_t)num_src * RADIX];
-    uint64_t *src_off = new uint64_t[(size_t)num_src * RADIX];
-    uint64_t run = 0;
-    for (int sidx = 0; sidx < num_src; ++sidx)
-        for (int b = 0; b < RADIX; ++b) { src_off[sidx * RADIX + b] = run; run += h_piece_counts[sidx * RADIX + b]; }
-    uint32_t nb = 0, np = 0, tile = 0;
-    uint64_t out_off = 0;
-    for (int b = 0; b < RADIX; ++b) {
-        uint64_t size = 0;
-        for (int sidx = 0; sidx < num_src; ++sidx) size += h_piece_counts[sidx * RADIX + b];
-        if (size == 0) continue;
-        const uint32_t tile_start = tile;
-        for (int sidx = 0; sidx < num_src; ++sidx) {
-            const uint64_t c = h_piece_counts[sidx * RADIX + b];
-            if (c == 0) continue;
-            hp[np++] = MsbPiece{(uint32_t)src_off[sidx * RADIX + b], (uint32_t)c, tile, nb};
-            tile += (uint32_t)((c + MSB_TILE - 1) / MSB_TILE);
-        }
-        hb[nb++] = MsbBucket{(uint32_t)out_off, (uint32_t)size, tile_start, tile - tile_start};
-        out_off += size;
+    // host side of what the level-0 classification does on one GPU: bucket list + pieces of level 1.  The tables
+    // live on the heap until a host callback behind the copies frees them, so the call never blocks the host: a
+    // caller that pipelines several finishes behind their exchanges enqueues them all at once.
+    struct HostTables {
+        MsbLevel hl[5];
+        MsbBucket hb[RADIX];
+        MsbPiece *hp;
+        ~HostTables() { delete[] hp; }
+    };
+    HostTables *ht = new (std::nothrow) HostTables{};
+    if (ht) ht->hp = new (std::nothrow) MsbPiece[(size_t)num_src * RADIX];
+    if (!ht || !ht->hp) { delete ht; return hipErrorOutOfMemory; }
+    uint64_t *src_off = new (std::nothrow) uint64_t[(size_t)num_src * RADIX];
+    if (!src_off) { delete ht; return hipErrorOutOfMemory; }
+    {   // the buffer holds source 0's pieces in byte order, then source 1's, ...
+        uint64_t run = 0;
+        for (int i = 0; i < num_src * RADIX; ++i) { src_off[i] = run; run += h_piece_counts[i]; }
     }
-    MsbLevel hl[5] = {};
-    hl[1].packed = ((unsigned long long)nb << 32) | tile;
-    hipError_t e = hipMemcpyAsync(ws.level, hl, sizeof(hl), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(ws.buckets[1], hb, nb * sizeof(MsbBucket), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(ws.pieces, hp, np * sizeof(MsbPiece), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);            // the host tables go out of scope below
-    delete[] hp;
+    uint32_t nb = 0, np = 0, tile = 0;
+    {
+        uint64_t out_off = 0;
+        for (int b = 0; b < RADIX; ++b) {
+            uint64_t size = 0;
+            for (int sidx = 0; sidx < num_src; ++sidx) size += h_piece_counts[sidx * RADIX + b];
+            if (size == 0) continue;
+            const uint32_t tile_start = tile;
+            for (int sidx = 0; sidx < num_src; ++sidx) {
+                const uint64_t c = h_piece_counts[sidx * RADIX + b];
+                if (c == 0) continue;
+                ht->hp[np++] = MsbPiece{(uint32_t)src_off[sidx * RADIX + b], (uint32_t)c, tile, nb};
+                tile += (uint32_t)((c + MSB_TILE - 1) / MSB_TILE);
+            }
+            ht->hb[nb++] = MsbBucket{(uint32_t)out_off, (uint32_t)size, tile_start, tile - tile_start};
+            out_off += size;
+        }
+    }
     delete[] src_off;
-    if (e != hipSuccess) return (int)e;
+    ht->hl[1].packed = ((unsigned long long)nb << 32) | tile;
+    hipError_t e = hipMemcpyAsync(ws.level, ht->hl, sizeof(ht->hl), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(ws.buckets[1], ht->hb, nb * sizeof(MsbBucket), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(ws.pieces, ht->hp, np * sizeof(MsbPiece), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipLaunchHostFunc(s, [](void *p) { delete static_cast<HostTables *>(p); }, ht);
+    if (e != hipSuccess) {             // the callback was not enqueued: wait for what was, then free here
+        (void)hipStreamSynchronize(s);
+        delete ht;
+        return (int)e;
+    }
 
     PassParams tw{};
     lsb_twiddle_masks(key_type, 0, true, true, tw);

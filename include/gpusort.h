@@ -171,7 +171,11 @@ int gs_segmented_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], 
  * byte order); h_piece_counts[num_src][256] (HOST memory) are the piece sizes.  The buckets are
  * picked up where they lie -- no regrouping pass -- and the sorted keys (in key_type's own
  * representation) land in d_keys_out; d_keys / d_vals are clobbered.  d_temp sized by
- * gs_msb_finish_temp_bytes.                                                            */
+ * gs_msb_finish_temp_bytes.  h_piece_counts is read before the call returns; the call itself
+ * is asynchronous on `stream` unless `synchronize` is set, so a host that cuts the exchange
+ * into several collectives can enqueue one finish per group of buckets behind its collective
+ * (pointers offset to the group's slice of the receive and output buffers, one d_temp per
+ * finish that may be in flight -- calls on one stream may share it).              */
 int gs_msb_first_pass_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys_in,
                           uint32_t *d_keys_out, const uint32_t *d_vals_in, uint32_t *d_vals_out,
                           uint64_t num_items, int key_type, uint64_t *d_bucket_counts, void *stream);
