@@ -31,4 +31,8 @@ struct KernelTimer {
     KernelTimer(int id, hipStream_t stream);
     ~KernelTimer();
 };
+// Zero `bytes` (a multiple of 8, at an 8-byte aligned address) with a kernel.  Used instead of hipMemsetAsync
+// everywhere a sort may be captured in a HIP graph: the memset node of a captured graph was seen not to take
+// effect from the second replay on (counters kept growing until the task lists overflowed); a kernel node does.
+hipError_t zero_async(void *p, size_t bytes, hipStream_t s);
 }  // namespace gs

@@ -781,7 +781,7 @@ static int lsb_run_passes(const LsbWorkspace &ws, uint64_t num_items, int begin_
                 hp.shift[q] = (uint32_t)(begin_bit + q * RADIX_BITS);
                 hp.bits[q] = (uint32_t)((end_bit - (int)hp.shift[q] < RADIX_BITS) ? end_bit - (int)hp.shift[q] : RADIX_BITS);
             }
-            hipError_t me = hipMemsetAsync(ws.totals4, 0, totals4_bytes(), s);
+            hipError_t me = zero_async(ws.totals4, totals4_bytes(), s);
             if (me != hipSuccess) return (int)me;
             KernelTimer kt(GS_K_LSB_UPSWEEP, s);
             const uint32_t g = p.num_tiles < 2048u ? p.num_tiles : 2048u;
@@ -790,7 +790,7 @@ static int lsb_run_passes(const LsbWorkspace &ws, uint64_t num_items, int begin_
             else
                 hipLaunchKernelGGL(lsb_hist4_kernel<false>, dim3(g), dim3(LSB_THREADS), 0, s, kin, ws.totals4, hp);
         }
-        hipError_t me = hipMemsetAsync(ws.status, 0, status_bytes(num_items), s);
+        hipError_t me = zero_async(ws.status, status_bytes(num_items), s);
         if (me != hipSuccess) return (int)me;
         const uint32_t *tot = ws.totals4 + pass * RADIX;
         {

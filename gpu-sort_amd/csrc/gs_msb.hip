@@ -1344,7 +1344,7 @@ int gs_msb_first_pass_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_key
     if (num_items >= (1ull << 32) || !d_bucket_counts) return hipErrorInvalidValue;
     if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
-    if (num_items == 0) return (int)hipMemsetAsync(d_bucket_counts, 0, RADIX * sizeof(uint64_t), s);
+    if (num_items == 0) return (int)zero_async(d_bucket_counts, RADIX * sizeof(uint64_t), s);
     if ((d_vals_in == nullptr) != (d_vals_out == nullptr) || !d_keys_in || !d_keys_out) return hipErrorInvalidValue;
     if (!d_temp || temp_bytes < lsb_temp_bytes(num_items)) return hipErrorInvalidValue;
     const LsbWorkspace lw = lsb_carve(d_temp, num_items);
@@ -1468,7 +1468,8 @@ int gs_segmented_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], 
     PassParams tw{};
     lsb_twiddle_masks(key_type, descending, true, true, tw);
 
-    hipError_t e = hipMemsetAsync(ws.level, 0, 5 * sizeof(MsbLevel), s);
+    static_assert(sizeof(MsbLevel) % 8 == 0, "levels are zeroed 8 bytes at a time");
+    hipError_t e = zero_async(ws.level, 5 * sizeof(MsbLevel), s);
     if (e != hipSuccess) return (int)e;
     { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
       const uint32_t g = (num_segments + 255u) / 256u;
@@ -1518,7 +1519,7 @@ int gs_shard_histogram_u32(const uint32_t *d_keys, uint64_t num_items, int bits,
     if (bits < 1 || bits > SHARD_MAX_BITS || !d_hist) return hipErrorInvalidValue;
     if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(d_hist, 0, sizeof(uint64_t) << bits, s);
+    hipError_t e = zero_async(d_hist, sizeof(uint64_t) << bits, s);
     if (e != hipSuccess) return (int)e;
     if (num_items == 0) return hipSuccess;
     if (!d_keys) return hipErrorInvalidValue;
@@ -1546,7 +1547,7 @@ int gs_shard_partition_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_ke
     if (num_items >= (1ull << 32)) return hipErrorInvalidValue;
     if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e0 = hipMemsetAsync(d_counts, 0, sizeof(uint64_t) * num_ranks, s);
+    hipError_t e0 = zero_async(d_counts, sizeof(uint64_t) * num_ranks, s);
     if (e0 != hipSuccess) return (int)e0;
     if (num_items == 0) return hipSuccess;
     if ((d_vals_in == nullptr) != (d_vals_out == nullptr) || !d_keys_in || !d_keys_out) return hipErrorInvalidValue;

@@ -129,6 +129,21 @@ KernelTimer::~KernelTimer()
 }
 }  // namespace gs
 
+namespace gs {
+__global__ void zero_kernel(unsigned long long *p, uint32_t n64)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n64; i += gridDim.x * blockDim.x) p[i] = 0ull;
+}
+hipError_t zero_async(void *p, size_t bytes, hipStream_t s)
+{
+    const uint32_t n64 = (uint32_t)(bytes / 8);
+    if (n64 == 0) return hipSuccess;
+    const uint32_t blocks = (n64 + 255u) / 256u;
+    hipLaunchKernelGGL(zero_kernel, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, s, (unsigned long long *)p, n64);
+    return hipGetLastError();
+}
+}  // namespace gs
+
 using namespace gs;
 
 extern "C" {
@@ -199,7 +214,7 @@ int gs_generate_u32(uint32_t *d_out, uint64_t num_items, int kind, uint64_t seed
 int gs_check_sorted_u32(const uint32_t *d_keys, uint64_t num_items, int descending, uint64_t *d_result, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(d_result, 0, 3 * sizeof(uint64_t), s);
+    hipError_t e = zero_async(d_result, 3 * sizeof(uint64_t), s);
     if (e != hipSuccess) return (int)e;
     if (num_items == 0) return hipSuccess;
     hipLaunchKernelGGL(check_sorted_kernel, dim3(stream_grid(num_items)), dim3(256), 0, s, d_keys, num_items,
@@ -211,7 +226,7 @@ int gs_check_pairs_enumerated_u32(const uint32_t *d_keys_in, const uint32_t *d_k
                                   uint64_t num_items, uint64_t *d_result, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(d_result, 0, 2 * sizeof(uint64_t), s);
+    hipError_t e = zero_async(d_result, 2 * sizeof(uint64_t), s);
     if (e != hipSuccess) return (int)e;
     if (num_items == 0) return hipSuccess;
     hipLaunchKernelGGL(check_pairs_enum_kernel, dim3(stream_grid(num_items)), dim3(256), 0, s, d_keys_in,

@@ -169,3 +169,34 @@ def test_all_ones_keys_next_to_padding(gs, cuda, oracle, n):
     vals = oracle.gen_enumerated(n)
     ks, vs = _msb_pairs(gs, keys, vals, cuda)
     assert oracle.msb_check_pairs_enumerated(keys, ks, vs) == 0
+
+
+@pytest.mark.parametrize("n,pairs", [(3000, False), (300007, False), (300007, True)])
+def test_msb_sort_is_capturable_in_a_hip_graph(gs, cuda, oracle, n, pairs):
+    """With synchronize=0 the MSB sort takes every decision on the device (bucket lists, task lists, grids
+    bounded on the host) -- the reference needs >= 3 blocking D2H round trips per pass (gpu_radix_sort.h:
+    426, generate_next_pass_block_assignments) -- so a call can be captured once and replayed on new data."""
+    keys1, keys2 = oracle.gen_uniform(n, seed=3), oracle.gen_zipf(n, seed=4)
+    src = to_dev(keys1, cuda)
+    a, b = src.clone(), torch.empty_like(src)
+    vsrc = to_dev(oracle.gen_enumerated(n), cuda) if pairs else None
+    va, vb = (vsrc.clone(), torch.empty_like(vsrc)) if pairs else (None, None)
+    temp = torch.empty(gs.lib.gs_msb_temp_bytes(n, int(pairs)), dtype=torch.uint8, device=cuda)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        gs.rdxsrt_unstable_sort(a, va, n, b, vb, pre_allocated_dm=temp, synchronize=False)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        a.copy_(src)
+        if pairs:
+            va.copy_(vsrc)
+        seq = gs.rdxsrt_unstable_sort(a, va, n, b, vb, pre_allocated_dm=temp, synchronize=False)
+    for keys in (keys1, keys2, keys2, keys1):
+        src.copy_(to_dev(keys, cuda))
+        g.replay()
+        torch.cuda.synchronize()
+        got = to_u32(seq.sorted_keys)[:n]
+        assert np.array_equal(got, np.sort(keys))
+        if pairs:
+            assert oracle.msb_check_pairs_enumerated(keys, got, to_u32(seq.sorted_values)[:n]) == 0

@@ -147,3 +147,41 @@ def test_segmented_errors(gs, cuda):
         gs.DeviceSegmentedRadixSort.SortKeys(temp, temp.numel(), dk, 100, 2, ob[:-1], ob[1:], 0, 33)
     with pytest.raises(ValueError):
         gs.DeviceSegmentedRadixSort.SortKeys(temp, temp.numel(), dk, 100, 2, ob[:-1].to(torch.int64), ob[1:])
+
+
+def test_segmented_sort_is_capturable_in_a_hip_graph(gs, cuda, oracle):
+    """No host-side decision depends on the segment sizes (they are classified on the device), so a call can be
+    captured in a HIP graph and replayed on new keys AND new segment offsets of the same count."""
+    n, nseg = 200003, 300
+    rng = np.random.default_rng(5)
+    S = gs.DeviceSegmentedRadixSort
+    src = torch.empty(n, dtype=torch.int32, device=cuda)
+    a, b = torch.empty_like(src), torch.empty_like(src)
+    ob = torch.empty(nseg, dtype=torch.int32, device=cuda)
+    oe = torch.empty(nseg, dtype=torch.int32, device=cuda)
+    dk = gs.DoubleBuffer(a, b)
+    nb = S.SortKeys(None, 0, dk, n, nseg, ob, oe)
+    temp = torch.empty(max(nb, 1), dtype=torch.uint8, device=cuda)
+    cases = []
+    for seed in (1, 2):
+        keys = oracle.gen_uniform(n, seed=seed)
+        offs = _random_offsets(rng, n, nseg)
+        cases.append((keys, offs))
+    keys, offs = cases[0]
+    src.copy_(to_dev(keys, cuda)); ob.copy_(torch.from_numpy(offs[:-1].astype(np.int32))); oe.copy_(torch.from_numpy(offs[1:].astype(np.int32)))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        a.copy_(src)
+        S.SortKeys(temp, nb, dk, n, nseg, ob, oe, 0, 32, key_type=gs.GS_KEY_U32)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    dk.selector = 0
+    with torch.cuda.graph(g, stream=side):
+        a.copy_(src)
+        S.SortKeys(temp, nb, dk, n, nseg, ob, oe, 0, 32, key_type=gs.GS_KEY_U32)
+    out = dk.Current()
+    for keys, offs in cases + cases[::-1]:                 # four replays: state left by one must not leak into the next
+        src.copy_(to_dev(keys, cuda)); ob.copy_(torch.from_numpy(offs[:-1].astype(np.int32))); oe.copy_(torch.from_numpy(offs[1:].astype(np.int32)))
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(to_u32(out)[:n], keys[_expected(oracle, keys, offs, 0, 32, False)])

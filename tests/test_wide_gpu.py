@@ -170,3 +170,29 @@ def test_large_int64_against_torch_sort(gs, cuda):
     assert int(out.sum()) == int(a.sum()) and int(torch.bitwise_xor(out[::2], out[1::2]).sum()) != 0
     del dk, dv, vout
     assert torch.equal(out, torch.sort(a).values)
+
+
+def test_wide_sort_is_capturable_in_a_hip_graph(gs, cuda):
+    """64-bit keys: captured once, replayed three times on new data in the same buffers."""
+    n = 150001
+    sets = [_keys64(n, seed, "u64") for seed in (11, 12, 13)]
+    src = _dev64(sets[0], cuda)
+    a, b = src.clone(), torch.empty_like(src)
+    dk = gs.DoubleBuffer(a, b)
+    nb = gs.DeviceRadixSort.SortKeys(None, 0, dk, n)
+    temp = torch.empty(max(nb, 1), dtype=torch.uint8, device=cuda)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        gs.DeviceRadixSort.SortKeys(temp, nb, dk, n, key_type=KT["u64"])
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    dk.selector = 0
+    with torch.cuda.graph(g, stream=side):
+        a.copy_(src)
+        gs.DeviceRadixSort.SortKeys(temp, nb, dk, n, key_type=KT["u64"])
+    out = dk.Current()
+    for keys in sets:
+        src.copy_(_dev64(keys, cuda))
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64)[:n], np.sort(keys))
