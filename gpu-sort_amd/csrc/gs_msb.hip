@@ -77,6 +77,9 @@ struct MsbWs {
     uint16_t *prefix16;                  // [max_tiles][256]
     MsbTask *tasks[MSB_NCLASS];
     MsbPiece *pieces;                    // [extra_pieces] (gs_msb_finish_u32 only)
+    // capacities of the lists above.  The sizing makes them sufficient; all the same every device-side append and
+    // every reader of a device-side count is bounded by them, so that a wrong count (a bug) gives a wrong result a
+    // test can catch instead of an out-of-bounds access (a GPU memory fault can take the whole node down)
     uint32_t max_buckets, max_tasks, max_tiles, stride;
 };
 
@@ -151,12 +154,14 @@ __global__ void msb_single_task_kernel(MsbWs ws, uint32_t n, int cls)
 // tile records of level L from its bucket list (one block per bucket and step)
 __global__ __launch_bounds__(256) void msb_expand_kernel(MsbWs ws, int L)
 {
-    const uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
+    uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
+    if (nb > ws.max_buckets) nb = ws.max_buckets;
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const MsbBucket B = ws.buckets[L & 1][b];
         for (uint32_t t = threadIdx.x; t < B.tiles; t += blockDim.x) {
             const uint32_t lo = B.offset + t * MSB_TILE, left = B.size - t * MSB_TILE;
-            ws.tiles[B.tile_start + t] = MsbTile{lo, left < (uint32_t)MSB_TILE ? left : (uint32_t)MSB_TILE, b, 0u};
+            if (B.tile_start + t < ws.max_tiles)
+                ws.tiles[B.tile_start + t] = MsbTile{lo, left < (uint32_t)MSB_TILE ? left : (uint32_t)MSB_TILE, b, 0u};
         }
     }
 }
@@ -170,7 +175,8 @@ __global__ __launch_bounds__(256) void msb_expand_pieces_kernel(MsbWs ws, uint32
         const uint32_t tiles = (P.size + MSB_TILE - 1) / MSB_TILE;
         for (uint32_t t = threadIdx.x; t < tiles; t += blockDim.x) {
             const uint32_t left = P.size - t * MSB_TILE;
-            ws.tiles[P.tile_start + t] = MsbTile{P.lo + t * MSB_TILE, left < (uint32_t)MSB_TILE ? left : (uint32_t)MSB_TILE, P.bucket, 0u};
+            if (P.tile_start + t < ws.max_tiles)
+                ws.tiles[P.tile_start + t] = MsbTile{P.lo + t * MSB_TILE, left < (uint32_t)MSB_TILE ? left : (uint32_t)MSB_TILE, P.bucket, 0u};
         }
     }
 }
@@ -215,7 +221,8 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int 
     __shared__ uint32_t lh[MSB_WAVES][SUB][RADIX + 1];
     __shared__ uint8_t tab[REMAP ? (1 << SHARD_MAX_BITS) : 4];
     if (REMAP) load_remap(ds, tab);
-    const uint32_t ntiles = (uint32_t)ws.level[L].packed;
+    uint32_t ntiles = (uint32_t)ws.level[L].packed;
+    if (ntiles > ws.max_tiles - MSB_WAVES) ntiles = ws.max_tiles - MSB_WAVES;      // never (see MsbWs)
     const uint32_t nchunks = ntiles / MSB_WAVES + 1;          // covers tile index `ntiles` too (see classify)
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
     uint32_t *my = lh[w][lane & (SUB - 1)];
@@ -278,7 +285,8 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int 
 __global__ __launch_bounds__(1024) void msb_scan_kernel(MsbWs ws, int L)
 {
     __shared__ uint32_t wsum[16];
-    const uint32_t nchunks = (uint32_t)ws.level[L].packed / MSB_WAVES + 1;
+    uint32_t nchunks = (uint32_t)ws.level[L].packed / MSB_WAVES + 1;
+    if (nchunks > ws.stride) nchunks = ws.stride;              // never (see MsbWs)
     uint32_t *row = ws.spine + (size_t)blockIdx.x * ws.stride;
     const int w = wave_id(), lane = lane_id();
     uint32_t carry = 0;
@@ -318,7 +326,8 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
     __shared__ uint8_t s_large[RADIX];
     __shared__ uint32_t s_tot[2], s_ccnt[MSB_NCLASS], s_cbase[MSB_NCLASS];
     __shared__ unsigned long long s_base64;
-    const uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
+    uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
+    if (nb > ws.max_buckets) nb = ws.max_buckets;              // never (see MsbWs)
     const int d = threadIdx.x;
     const uint32_t cap_max = msb_class_cap(nclass - 1);
     const uint32_t rb = 24u - 8u * (uint32_t)L;                  // bits below this level's byte
@@ -387,9 +396,11 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
         __syncthreads();
         if (is_large) {
             new_bucket = (uint32_t)(s_base64 >> 32) + bidx;
-            ws.buckets[(L + 1) & 1][new_bucket] = MsbBucket{abs, c, (uint32_t)s_base64 + tidx, tiles};
+            if (new_bucket < ws.max_buckets)
+                ws.buckets[(L + 1) & 1][new_bucket] = MsbBucket{abs, c, (uint32_t)s_base64 + tidx, tiles};
         } else if (tsize) {
-            ws.tasks[cls][s_cbase[cls] + task_local] = MsbTask{abs, tsize, rb + (s_nsub[d] > 1 ? 8u : 0u), 0u};
+            if (s_cbase[cls] + task_local < ws.max_tasks)
+                ws.tasks[cls][s_cbase[cls] + task_local] = MsbTask{abs, tsize, rb + (s_nsub[d] > 1 ? 8u : 0u), 0u};
         }
     }
 }
@@ -686,7 +697,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_so
     constexpr int ONEPASS_BITS = local_b1(KPT * THREADS * (HAS_VALUES ? 2 : 1)) + 2;
     static_assert(KPT * THREADS >= (1 << LOCAL_B1) && KPT * THREADS >= WAVES * RADIX, "counters must fit the staging buffer");
     __shared__ __attribute__((aligned(16))) LocalSmem<THREADS, KPT, HAS_VALUES> sm;
-    const uint32_t ntasks = ws.level[L].task_count[cls];
+    uint32_t ntasks = ws.level[L].task_count[cls];
+    if (ntasks > ws.max_tasks) ntasks = ws.max_tasks;
     if (MODE == LS_FLAGGED && ws.level[L].flagged == 0u) return;     // nothing was left over (the usual case)
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     uint32_t *my = sm.whist[w];
@@ -1209,6 +1221,7 @@ int small_stable_sort(void *scratch, size_t scratch_bytes, const uint32_t *kin, 
     MsbWs ws{};
     ws.level = (MsbLevel *)scratch;
     for (int c = 0; c < MSB_NCLASS; ++c) ws.tasks[c] = (MsbTask *)((char *)scratch + 256);
+    ws.max_tasks = 1;
     KernelTimer kt(GS_K_MSB_LOCAL_SORT, s);
     hipLaunchKernelGGL(msb_small_task_kernel, dim3(1), dim3(64), 0, s, ws.level, ws.tasks[cls], n, cls,
                        (uint32_t)(end_bit - begin_bit), (uint32_t)begin_bit);
@@ -1314,12 +1327,13 @@ __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *
             uint32_t first = 0;
             if (count_lower_mask(m) == 0 && cls == c) first = atomicAdd(&ws.level[1].task_count[c], (uint32_t)__popcll(m));
             first = (uint32_t)__shfl((int)first, __builtin_ctzll(m), WAVE);
-            if (cls == c) ws.tasks[c][first + count_lower_mask(m)] = MsbTask{b, size, sort_bits, shift0};
+            if (cls == c && first + count_lower_mask(m) < ws.max_tasks)
+                ws.tasks[c][first + count_lower_mask(m)] = MsbTask{b, size, sort_bits, shift0};
         }
         if (size > cap_max) {
             const uint32_t tiles = (size + MSB_TILE - 1) / MSB_TILE;
             const unsigned long long old = atomicAdd(&ws.level[1].packed, (1ull << 32) | tiles);
-            ws.buckets[1][(uint32_t)(old >> 32)] = MsbBucket{b, size, (uint32_t)old, tiles};
+            if ((uint32_t)(old >> 32) < ws.max_buckets) ws.buckets[1][(uint32_t)(old >> 32)] = MsbBucket{b, size, (uint32_t)old, tiles};
         }
     }
 }
