@@ -1307,14 +1307,18 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
 // that is partitioned once per 8-bit digit, least significant first, with the level machinery above.
 __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *__restrict__ seg_begin,
                                                            const int *__restrict__ seg_end, uint32_t nseg, int nclass,
-                                                           uint32_t sort_bits, uint32_t shift0)
+                                                           uint32_t sort_bits, uint32_t shift0, uint32_t num_items)
 {
     const uint32_t cap_max = msb_class_cap(nclass - 1);
     for (uint32_t base = blockIdx.x * blockDim.x; base < nseg; base += gridDim.x * blockDim.x) {
         const uint32_t sg = base + threadIdx.x;
         uint32_t b = 0, size = 0;
         if (sg < nseg) {
-            const int lo = seg_begin[sg], hi = seg_end[sg];
+            int lo = seg_begin[sg], hi = seg_end[sg];
+            // offsets outside [0, num_items] are the caller's error; clamp them so that they cannot become
+            // out-of-bounds accesses
+            if (lo < 0) lo = 0;
+            if (hi > (int)num_items) hi = (int)num_items;
             if (hi > lo) { b = (uint32_t)lo; size = (uint32_t)(hi - lo); }
         }
         int cls = -1;
@@ -1488,7 +1492,7 @@ int gs_segmented_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], 
     { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
       const uint32_t g = (num_segments + 255u) / 256u;
       hipLaunchKernelGGL(seg_classify_kernel, dim3(g < 4096u ? g : 4096u), dim3(256), 0, s, ws, d_begin_offsets, d_end_offsets,
-                         num_segments, nclass, (uint32_t)num_bits, (uint32_t)begin_bit); }
+                         num_segments, nclass, (uint32_t)num_bits, (uint32_t)begin_bit, (uint32_t)num_items); }
     // small segments: one stable local sort each, straight into the final buffer
     if (pairs) launch_local_sorts<true, true>(ws, 1, num_segments, d_keys[sel], d_keys[fin], d_vals[sel], d_vals[fin], tw.f32_in,
                                               tw.xor_in, tw.f32_out, tw.xor_out, s);

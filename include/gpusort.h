@@ -151,7 +151,7 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes,
  * DeviceSegmentedRadixSortKernel, dispatch_radix_sort.cuh:321-432): every segment
  * [d_begin_offsets[i], d_end_offsets[i]) of the keys (and values) is sorted on its own, stably,
  * on bits [begin_bit, end_bit); segments must not overlap, empty ones are fine, and positions
- * outside every segment are not written.  DoubleBuffer semantics as gs_lsb_sort_u32 (both
+ * outside every segment are not written (offsets outside [0, num_items] are clamped on the device).  DoubleBuffer semantics as gs_lsb_sort_u32 (both
  * halves may be clobbered, the result is d_keys[*selector] after the call).  num_items < 2^31.
  * Segments that fit one workgroup (<= 17408 keys, 9216 pairs) cost one read and one write; the
  * larger ones are partitioned together, one 8-bit digit per pass.                       */

@@ -149,6 +149,31 @@ def test_segmented_errors(gs, cuda):
         gs.DeviceSegmentedRadixSort.SortKeys(temp, temp.numel(), dk, 100, 2, ob[:-1].to(torch.int64), ob[1:])
 
 
+def test_segment_offsets_out_of_range_are_clamped(gs, cuda, oracle):
+    """Offsets outside [0, num_items] are a caller error (CUB: undefined); here they are clamped on the device, so
+    the call sorts what lies inside the array and touches nothing else."""
+    n = 5000
+    keys = oracle.gen_uniform(n, seed=9)
+    guard = 4096
+    buf = torch.full((n + 2 * guard,), 0x5A5A5A5A, dtype=torch.int32, device=cuda)
+    alt = torch.full_like(buf, 0x5A5A5A5A)
+    buf[guard:guard + n] = to_dev(keys, cuda)
+    dk = gs.DoubleBuffer(buf[guard:guard + n], alt[guard:guard + n])
+    ob = torch.tensor([-700, 1000, 4000], dtype=torch.int32, device=cuda)
+    oe = torch.tensor([1000, 4000, n + 900], dtype=torch.int32, device=cuda)
+    S = gs.DeviceSegmentedRadixSort
+    nb = S.SortKeys(None, 0, dk, n, 3, ob, oe)
+    temp = torch.empty(max(nb, 1), dtype=torch.uint8, device=cuda)
+    S.SortKeys(temp, nb, dk, n, 3, ob, oe, 0, 32, key_type=gs.GS_KEY_U32)
+    torch.cuda.synchronize()
+    got = to_u32(dk.Current())[:n]
+    exp = np.concatenate([np.sort(keys[0:1000]), np.sort(keys[1000:4000]), np.sort(keys[4000:n])])
+    assert np.array_equal(got, exp)
+    for t in (buf, alt):
+        g = t.cpu().numpy()
+        assert np.all(g[:guard] == 0x5A5A5A5A) and np.all(g[guard + n:] == 0x5A5A5A5A)
+
+
 def test_segmented_sort_is_capturable_in_a_hip_graph(gs, cuda, oracle):
     """No host-side decision depends on the segment sizes (they are classified on the device), so a call can be
     captured in a HIP graph and replayed on new keys AND new segment offsets of the same count."""
