@@ -47,6 +47,8 @@ constexpr uint32_t MSB_MAX_GRID = 16384;           // blocks per launch; kernels
 __host__ __device__ constexpr int msb_class_threads(int c) { return c < 2 ? 512 : 1024; }
 __host__ __device__ constexpr int msb_class_kpt(int c) { return c == 0 ? 4 : c == 1 ? 9 : c == 2 ? 9 : 17; }
 __host__ __device__ constexpr uint32_t msb_class_cap(int c) { return (uint32_t)(msb_class_kpt(c) * msb_class_threads(c)); }
+// tiles of a range of x keys; x + MSB_TILE - 1 would wrap for ranges within one tile of 2^32
+__host__ __device__ constexpr uint32_t msb_tiles_of(uint32_t x) { return x / (uint32_t)MSB_TILE + (x % (uint32_t)MSB_TILE ? 1u : 0u); }
 // pairs keep {key,value} in LDS, so their largest class is 9216 (144 KiB would not leave room for two blocks)
 __host__ __device__ constexpr int msb_num_classes(bool has_values) { return has_values ? 3 : 4; }
 
@@ -136,10 +138,10 @@ __global__ void msb_init_kernel(MsbWs ws, uint32_t n)
     const int t = threadIdx.x;
     if (t < 5) {
         MsbLevel z{};
-        if (t == 0) z.packed = (1ull << 32) | ((n + MSB_TILE - 1) / MSB_TILE);
+        if (t == 0) z.packed = (1ull << 32) | msb_tiles_of(n);
         ws.level[t] = z;
     }
-    if (t == 0) ws.buckets[0][0] = MsbBucket{0u, n, 0u, (n + MSB_TILE - 1) / MSB_TILE};
+    if (t == 0) ws.buckets[0][0] = MsbBucket{0u, n, 0u, msb_tiles_of(n)};
 }
 
 // direct path for arrays that fit one workgroup: a single task on all 32 bits
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void msb_expand_pieces_kernel(MsbWs ws, uint32
 {
     for (uint32_t q = blockIdx.x; q < npieces; q += gridDim.x) {
         const MsbPiece P = ws.pieces[q];
-        const uint32_t tiles = (P.size + MSB_TILE - 1) / MSB_TILE;
+        const uint32_t tiles = msb_tiles_of(P.size);
         for (uint32_t t = threadIdx.x; t < tiles; t += blockDim.x) {
             const uint32_t left = P.size - t * MSB_TILE;
             if (P.tile_start + t < ws.max_tiles)
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
         const uint32_t tsize = s_task[d];
         int cls = 0;
         if (tsize) while (msb_class_cap(cls) < tsize) ++cls;
-        const uint32_t tiles = is_large ? (c + MSB_TILE - 1) / MSB_TILE : 0u;
+        const uint32_t tiles = is_large ? msb_tiles_of(c) : 0u;
         // exclusive prefixes inside the block (bucket index, tile index) keep tile_start sorted
         const uint32_t bidx = block_exclusive_scan_256(is_large ? 1u : 0u, scratch, &s_tot[0]);
         const uint32_t tidx = block_exclusive_scan_256(tiles, scratch, &s_tot[1]);
@@ -1335,7 +1337,7 @@ __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *
                 ws.tasks[c][first + count_lower_mask(m)] = MsbTask{b, size, sort_bits, shift0};
         }
         if (size > cap_max) {
-            const uint32_t tiles = (size + MSB_TILE - 1) / MSB_TILE;
+            const uint32_t tiles = msb_tiles_of(size);
             const unsigned long long old = atomicAdd(&ws.level[1].packed, (1ull << 32) | tiles);
             if ((uint32_t)(old >> 32) < ws.max_buckets) ws.buckets[1][(uint32_t)(old >> 32)] = MsbBucket{b, size, (uint32_t)old, tiles};
         }
@@ -1576,7 +1578,7 @@ int gs_shard_partition_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_ke
     PassParams tw{};
     lsb_twiddle_masks(key_type, 0, true, true, tw);
     const DigitSel dsel{0, d_dest_of_bin, 32 - bits, tw.f32_in, tw.xor_in, 8, 0};
-    const uint32_t tiles = (n + MSB_TILE - 1) / MSB_TILE;
+    const uint32_t tiles = msb_tiles_of(n);
     const uint32_t grid = tiles;   // the tile count is known here: one tile per block, dispatched in order
     (void)d_bin_hist;              // per-tile counts are needed now: the keys are always read once more
     KernelTimer kt(GS_K_SHARD, s);

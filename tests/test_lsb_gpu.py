@@ -372,3 +372,19 @@ def test_sort_is_capturable_in_a_hip_graph(gs, cuda, oracle, n):
     src.copy_(to_dev(keys2, cuda))
     g.replay(); torch.cuda.synchronize()
     assert np.array_equal(to_u32(out)[:n], np.sort(keys2))
+
+
+def test_index_type_limit(cuda):
+    """num_items up to 2^32 - 1 (the ABI's limit: one 32-bit index type, as the reference's IndexT): 2^32 - 24583
+    uniform keys through LSB and MSB, and 2^32 - 1 equal keys (one bucket of almost 2^32 keys at every MSB level;
+    tile counts must not wrap).  Device-side property checks; run in a child process so that its ~50 GiB of
+    buffers are gone when it returns."""
+    import os, subprocess, sys
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * (1 << 30):
+        pytest.skip("needs 80 GiB of free device memory")
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "near_2p32.py")
+    for args in (["lsb", "msb"], ["--max-const", "lsb", "msb", "msb_pairs"]):
+        out = subprocess.run([sys.executable, tool] + args, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        assert out.stdout.count("-> OK") == len([a for a in args if not a.startswith("--")])
