@@ -1,0 +1,185 @@
+"""Randomised parity campaign on the GPU: LSB / MSB / segmented sorts of random sizes, key types, bit ranges,
+directions and key distributions against torch's stable sort on the same device (an implementation independent
+of both the library and the oracle).  usage: python tools/fuzz.py [iterations] [seed]
+Exit code 1 and the failing case on the first mismatch."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import gpu_sort_amd as gs
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+dev = torch.device("cuda:0")
+KT = {"u32": gs.GS_KEY_U32, "i32": gs.GS_KEY_I32, "f32": gs.GS_KEY_F32}
+EDGES = [0, 1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4607, 4608, 4609, 6911, 6912, 6913, 8191, 8192, 8193,
+         9215, 9216, 9217, 16383, 16384, 17407, 17408, 17409, 65535, 65536, 65537, 8192 * 9 - 1, 8192 * 17 + 5,
+         1 << 18, (1 << 20) + 3, 8192 * 2048, 8192 * 2048 + 1, (1 << 22) + 12345]
+
+
+def pick_n():
+    r = rng.random()
+    if r < 0.35:
+        return int(rng.choice(EDGES)) + int(rng.integers(-3, 4)) * int(rng.random() < 0.3)
+    if r < 0.7:
+        return int(rng.integers(0, 40000))
+    if r < 0.95:
+        return int(rng.integers(40000, 3_000_000))
+    return int(rng.integers(3_000_000, 20_000_000))
+
+
+def make_keys(n, kind):
+    g = torch.Generator(device=dev); g.manual_seed(int(rng.integers(0, 2**31)))
+    def rnd():
+        return torch.randint(-2**31, 2**31, (n,), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+    if kind == "uniform":
+        k = rnd()
+    elif kind.startswith("and"):
+        k = rnd()
+        for _ in range(int(kind[3:])):
+            k &= rnd()
+    elif kind == "few":
+        vals = rnd()[:max(1, int(rng.integers(1, 9)))] if n else rnd()
+        k = vals[torch.randint(0, max(1, vals.numel()), (n,), device=dev, generator=g)] if n else rnd()
+    elif kind == "const":
+        k = torch.full((n,), int(rng.integers(-2**31, 2**31)), dtype=torch.int32, device=dev)
+    elif kind == "ones_heavy":
+        k = rnd()
+        k[torch.rand(n, device=dev, generator=g) < 0.5] = -1
+    elif kind == "sorted":
+        k = torch.sort(rnd())[0]
+    elif kind == "reverse":
+        k = torch.sort(rnd(), descending=True)[0]
+    elif kind == "low_bytes":
+        k = rnd() & 0xFFFF
+    else:   # hot top byte
+        k = (rnd() & 0x00FFFFFF) | (int(rng.integers(0, 128)) << 24)
+    return k.contiguous()
+
+
+def twiddled(keys, kt):
+    """order-preserving unsigned image of the keys, as int64"""
+    b = keys.to(torch.int64) & 0xFFFFFFFF
+    if kt == "u32":
+        return b
+    if kt == "i32":
+        return b ^ 0x80000000
+    neg = keys < 0                                  # f32 bit patterns: flip all bits of negatives, the sign of the rest
+    return torch.where(neg, b ^ 0xFFFFFFFF, b ^ 0x80000000)
+
+
+def ref_perm(keys, kt, begin, end, desc, seg_id=None):
+    width = end - begin
+    d = (twiddled(keys, kt) >> begin) & ((1 << width) - 1) if width > 0 else torch.zeros_like(keys, dtype=torch.int64)
+    if desc:
+        d = ((1 << width) - 1) - d if width > 0 else d
+    if seg_id is not None:
+        d = d + (seg_id << 32)
+    return torch.sort(d, stable=True)[1]
+
+
+def fail(msg, **case):
+    print("MISMATCH:", msg, case, flush=True)
+    sys.exit(1)
+
+
+KINDS = ["uniform", "and1", "and3", "and6", "and10", "few", "const", "ones_heavy", "sorted", "reverse", "low_bytes", "hot"]
+counts = {}
+for it in range(iters):
+    algo = str(rng.choice(["lsb", "lsb", "msb", "msb", "seg"]))
+    pairs = bool(rng.random() < 0.5)
+    n = max(0, pick_n())
+    kind = str(rng.choice(KINDS))
+    kt = str(rng.choice(["u32", "u32", "i32", "f32"]))
+    keys = make_keys(n, kind)
+    if kt == "f32" and n:                            # no NaNs (the reference's tests generate none): clear them
+        f = keys.view(torch.float32)
+        keys = torch.where(torch.isnan(f), torch.zeros_like(keys), keys).contiguous()
+    vals = torch.randperm(n, device=dev).to(torch.int32) if (pairs and n and rng.random() < 0.5) else torch.arange(n, dtype=torch.int32, device=dev)
+    case = dict(it=it, algo=algo, pairs=pairs, n=n, kind=kind, kt=kt, seed=seed)
+    counts[algo] = counts.get(algo, 0) + 1
+    a, b = keys.clone(), torch.full_like(keys, 0x3C3C3C3C)
+    va, vb = (vals.clone(), torch.full_like(vals, 0x3C3C3C3C)) if pairs else (None, None)
+    if algo == "msb":
+        seq = gs.rdxsrt_unstable_sort(a, va, n, b, vb, key_type=KT[kt])
+        if n == 0:
+            continue
+        perm = ref_perm(keys, kt, 0, 32, False)
+        if not torch.equal(seq.sorted_keys[:n], keys[perm]):
+            fail("msb keys", **case)
+        if pairs:                                   # unstable: compare (key, value) pairs as multisets per key
+            got = (twiddled(seq.sorted_keys[:n], kt) << 32) | (seq.sorted_values[:n].to(torch.int64) & 0xFFFFFFFF)
+            exp = (twiddled(keys, kt) << 32) | (vals.to(torch.int64) & 0xFFFFFFFF)
+            if not torch.equal(torch.sort(got)[0], torch.sort(exp)[0]):
+                fail("msb values", **case)
+        continue
+    desc = bool(rng.random() < 0.4)
+    if rng.random() < 0.5:
+        begin, end = 0, 32
+    else:
+        begin = int(rng.integers(0, 32)); end = int(rng.integers(begin, 33))
+    case.update(desc=desc, begin=begin, end=end)
+    dk = gs.DoubleBuffer(a, b)
+    dv = gs.DoubleBuffer(va, vb) if pairs else None
+    if algo == "lsb":
+        R = gs.DeviceRadixSort
+        fn = (R.SortPairsDescending if desc else R.SortPairs) if pairs else (R.SortKeysDescending if desc else R.SortKeys)
+        args = (dk, dv, n) if pairs else (dk, n)
+        nb = fn(None, 0, *args)
+        temp = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+        fn(temp, nb, *args, begin, end, key_type=KT[kt])
+        if n == 0:
+            continue
+        if os.environ.get("FUZZ_SELFTEST") and n > 2:       # negative control: the campaign must notice this
+            dk.Current()[n // 2] ^= 1
+        perm = ref_perm(keys, kt, begin, end, desc)
+        if not torch.equal(dk.Current()[:n], keys[perm]):
+            fail("lsb keys", **case)
+        if pairs and not torch.equal(dv.Current()[:n], vals[perm]):
+            fail("lsb values (stability)", **case)
+        continue
+    # segmented
+    if n == 0 or n >= (1 << 31):
+        continue
+    nseg = int(rng.choice([1, 2, 7, 100, 1000, max(1, n // 50)]))
+    cuts = np.sort(rng.integers(0, n + 1, size=nseg - 1)) if nseg > 1 else np.zeros(0, np.int64)
+    offs = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    begin_offs, end_offs = offs[:-1].copy(), offs[1:].copy()
+    if rng.random() < 0.3 and nseg > 2:              # leave gaps: shrink some segments
+        shrink = rng.random(nseg) < 0.3
+        end_offs = np.where(shrink, begin_offs + (end_offs - begin_offs) // 2, end_offs)
+    case.update(nseg=nseg)
+    ob = torch.from_numpy(begin_offs.astype(np.int32)).to(dev); oe = torch.from_numpy(end_offs.astype(np.int32)).to(dev)
+    S = gs.DeviceSegmentedRadixSort
+    fn = (S.SortPairsDescending if desc else S.SortPairs) if pairs else (S.SortKeysDescending if desc else S.SortKeys)
+    args = (dk, dv, n, nseg, ob, oe) if pairs else (dk, n, nseg, ob, oe)
+    nb = fn(None, 0, *args)
+    temp = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+    fn(temp, nb, *args, begin, end, key_type=KT[kt])
+    # expected: positions inside a segment take the segment's stable order, the others are not part of the result
+    seg_id = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    inside = torch.zeros(n, dtype=torch.bool, device=dev)
+    lens = torch.from_numpy(end_offs - begin_offs).to(dev)
+    starts = torch.from_numpy(begin_offs).to(dev)
+    ids = torch.repeat_interleave(torch.arange(nseg, device=dev), lens)
+    pos = torch.repeat_interleave(starts, lens) + (torch.arange(int(lens.sum()), device=dev) - torch.repeat_interleave(torch.cumsum(lens, 0) - lens, lens))
+    seg_id[pos] = ids; inside[pos] = True
+    width = end - begin
+    d = (twiddled(keys, kt) >> begin) & ((1 << width) - 1) if width > 0 else torch.zeros(n, dtype=torch.int64, device=dev)
+    if desc and width > 0:
+        d = ((1 << width) - 1) - d
+    comp = torch.where(inside, (seg_id << 32) + d, torch.full_like(d, 1 << 62))
+    perm = torch.sort(comp, stable=True)[1][: int(inside.sum())]        # elements of segment 0 in order, then 1, ...
+    order = torch.sort(torch.where(inside, seg_id, torch.full_like(seg_id, 1 << 40)), stable=True)[1][: int(inside.sum())]
+    exp_k = keys.clone(); exp_k[order] = keys[perm]
+    got_k = dk.Current()[:n]
+    if not torch.equal(got_k[inside], exp_k[inside]):
+        fail("segmented keys", **case)
+    if pairs:
+        exp_v = vals.clone(); exp_v[order] = vals[perm]
+        if not torch.equal(dv.Current()[:n][inside], exp_v[inside]):
+            fail("segmented values", **case)
+    if (it + 1) % 100 == 0:
+        print(f"{it + 1} cases ok {counts}", flush=True)
+torch.cuda.synchronize()
+print(f"ALL {iters} CASES OK (seed {seed}) {counts}", flush=True)
