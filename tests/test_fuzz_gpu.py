@@ -1,4 +1,4 @@
-"""Randomised parity campaign (tools/fuzz.py): LSB / MSB / segmented sorts of random sizes (dense around every
+"""Randomised parity campaign (tools/fuzz.py): LSB / MSB / segmented / 64-bit sorts of random sizes (dense around every
 class, tile and chunk boundary), key types, bit ranges, directions and key distributions, checked on the device
 against torch's stable sort -- an implementation independent of the library and of the oracle.  The model is the
 reference's own randomised sweeps (test_device_radix_sort.cu:1034-1046 sizes shrinking at random,

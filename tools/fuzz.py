@@ -1,5 +1,5 @@
 """Randomised parity campaign on the GPU: LSB / MSB / segmented sorts of random sizes, key types, bit ranges,
-directions and key distributions against torch's stable sort on the same device (an implementation independent
+directions and key distributions, and the 64-bit configurations of the wide LSB sort, against torch's stable sort on the same device (an implementation independent
 of both the library and the oracle).  usage: python tools/fuzz.py [iterations] [seed]
 Exit code 1 and the failing case on the first mismatch."""
 import os, sys
@@ -83,10 +83,90 @@ def fail(msg, **case):
     sys.exit(1)
 
 
+MIN64 = -(1 << 63)
+
+
+def wide_case(it):
+    """gs_lsb_sort_wide: 64-bit keys (u64 / i64 / f64) with no, 32-bit or 64-bit values, or i32 keys with i64 values"""
+    n = min(max(0, pick_n()), 4_000_000)
+    g = torch.Generator(device=dev); g.manual_seed(int(rng.integers(0, 2**31)))
+    combo = str(rng.choice(["k64", "k64v32", "k64v64", "k32v64"]))
+    kt = str(rng.choice(["u64", "i64", "f64"])) if combo != "k32v64" else str(rng.choice(["u32", "i32"]))
+    kbits = 64 if combo != "k32v64" else 32
+    def rnd64():
+        hi = torch.randint(-2**31, 2**31, (n,), dtype=torch.int64, device=dev, generator=g)
+        lo = torch.randint(0, 2**32, (n,), dtype=torch.int64, device=dev, generator=g)
+        return (hi << 32) | lo
+    if kbits == 64:
+        keys = rnd64()
+        for _ in range(int(rng.choice([0, 0, 1, 3, 8]))):
+            keys &= rnd64()
+        if rng.random() < 0.15:
+            keys = keys & 0xFFFF                                  # many duplicates, constant high digits
+        if kt == "f64" and n:
+            f = keys.view(torch.float64)
+            keys = torch.where(torch.isnan(f), torch.zeros_like(keys), keys)
+    else:
+        keys = make_keys(n, str(rng.choice(KINDS)))
+    keys = keys.contiguous()
+    vdt = {"k64": None, "k64v32": torch.int32, "k64v64": torch.int64, "k32v64": torch.int64}[combo]
+    vals = None if vdt is None else (torch.arange(n, device=dev).to(vdt) * (3 if vdt == torch.int64 else 1))
+    desc = bool(rng.random() < 0.4)
+    if rng.random() < 0.5:
+        begin, end = 0, kbits
+    else:
+        begin = int(rng.integers(0, kbits)); end = int(rng.integers(begin, kbits + 1))
+    case = dict(it=it, algo="wide", combo=combo, n=n, kt=kt, desc=desc, begin=begin, end=end, seed=seed)
+    ktid = {"u32": gs.GS_KEY_U32, "i32": gs.GS_KEY_I32, "u64": 3, "i64": 4, "f64": 5}[kt]
+    dk = gs.DoubleBuffer(keys.clone(), torch.empty_like(keys))
+    dv = gs.DoubleBuffer(vals.clone(), torch.empty_like(vals)) if vals is not None else None
+    R = gs.DeviceRadixSort
+    fn = (R.SortPairsDescending if desc else R.SortPairs) if dv is not None else (R.SortKeysDescending if desc else R.SortKeys)
+    args = (dk, dv, n) if dv is not None else (dk, n)
+    nb = fn(None, 0, *args)
+    temp = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+    fn(temp, nb, *args, begin, end, key_type=ktid)
+    if n == 0:
+        return
+    # order-preserving image of the keys whose SIGNED order is the key order
+    if kbits == 32:
+        img = twiddled(keys, kt)                                  # 0 .. 2^32-1 as int64
+        U = img
+    else:
+        b = keys
+        if kt == "u64":
+            U = b
+        elif kt == "i64":
+            U = b ^ MIN64
+        else:
+            U = torch.where(b < 0, ~b, b ^ MIN64)
+        img = U ^ MIN64
+    width = end - begin
+    if width == kbits:
+        d = img
+        if desc:
+            d = ~d if kbits == 64 else ((1 << 32) - 1) - d
+    elif width == 0:
+        d = torch.zeros_like(img)
+    else:
+        d = (U >> begin) & ((1 << width) - 1)
+        if desc:
+            d = ((1 << width) - 1) - d
+    perm = torch.sort(d, stable=True)[1]
+    if not torch.equal(dk.Current()[:n], keys[perm]):
+        fail("wide keys", **case)
+    if dv is not None and not torch.equal(dv.Current()[:n], vals[perm]):
+        fail("wide values (stability)", **case)
+
+
 KINDS = ["uniform", "and1", "and3", "and6", "and10", "few", "const", "ones_heavy", "sorted", "reverse", "low_bytes", "hot"]
 counts = {}
 for it in range(iters):
-    algo = str(rng.choice(["lsb", "lsb", "msb", "msb", "seg"]))
+    algo = str(rng.choice(["lsb", "lsb", "msb", "msb", "seg", "wide"]))
+    if algo == "wide":
+        counts[algo] = counts.get(algo, 0) + 1
+        wide_case(it)
+        continue
     pairs = bool(rng.random() < 0.5)
     n = max(0, pick_n())
     kind = str(rng.choice(KINDS))
