@@ -49,8 +49,12 @@ __host__ __device__ constexpr int msb_class_kpt(int c) { return c == 0 ? 4 : c =
 __host__ __device__ constexpr uint32_t msb_class_cap(int c) { return (uint32_t)(msb_class_kpt(c) * msb_class_threads(c)); }
 // tiles of a range of x keys; x + MSB_TILE - 1 would wrap for ranges within one tile of 2^32
 __host__ __device__ constexpr uint32_t msb_tiles_of(uint32_t x) { return x / (uint32_t)MSB_TILE + (x % (uint32_t)MSB_TILE ? 1u : 0u); }
-// pairs keep {key,value} in LDS, so their largest class is 9216 (144 KiB would not leave room for two blocks)
-__host__ __device__ constexpr int msb_num_classes(bool has_values) { return has_values ? 3 : 4; }
+// pairs keep {key,value} in LDS: their 17408 class takes 139 KiB, i.e. one 1024-thread workgroup per CU (still 7 ms
+// cheaper at 2^30 uniform pairs than the third partition level that a largest class of 9216 made necessary)
+#ifndef GS_PAIR_CLASSES
+#define GS_PAIR_CLASSES 4      // 4: pairs also get the 17408 class (139 KiB of LDS, one 1024-thread workgroup per CU)
+#endif
+__host__ __device__ constexpr int msb_num_classes(bool has_values) { return has_values ? GS_PAIR_CLASSES : 4; }
 
 struct MsbBucket { uint32_t offset, size, tile_start, tiles; }; // a bucket still to be partitioned (output offset, keys, its tiles)
 struct MsbPiece { uint32_t lo, size, tile_start, bucket; };     // multi-GPU: a bucket arrives in one piece per source rank
@@ -689,7 +693,7 @@ struct LocalSmem {
 enum { LS_ALL = 0, LS_ONEPASS = 1, LS_FLAGGED = 2 };
 constexpr uint32_t LS_FLAG = 0x80000000u;
 template <int THREADS, int KPT, bool HAS_VALUES, bool STABLE = false, int MODE = LS_ALL>
-__global__ __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 4) void msb_local_sort_kernel(
+__global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 9)) ? 8 : 4) void msb_local_sort_kernel(
     MsbWs ws, int L, int cls, const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k, const uint32_t *__restrict__ src_v,
     uint32_t *__restrict__ dst_v, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out)
 {
@@ -1139,7 +1143,7 @@ static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uin
     GS_LS(0, HAS_VALUES);
     GS_LS(1, HAS_VALUES);
     GS_LS(2, HAS_VALUES);
-    if (!HAS_VALUES) GS_LS(3, false);
+    if (!HAS_VALUES || GS_PAIR_CLASSES > 3) GS_LS(3, HAS_VALUES);
 #undef GS_LS
 #undef GS_LS1
 }
@@ -1229,7 +1233,7 @@ int small_stable_sort(void *scratch, size_t scratch_bytes, const uint32_t *kin, 
                        (uint32_t)(end_bit - begin_bit), (uint32_t)begin_bit);
 #define GS_SM(C, HV) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV, true, LS_ALL>), dim3(1), \
                                         dim3(msb_class_threads(C)), 0, s, ws, 0, C, kin, kout, vin, vout, f32_in, xor_in, f32_out, xor_out)
-    if (pairs) { if (cls == 0) GS_SM(0, true); else if (cls == 1) GS_SM(1, true); else GS_SM(2, true); }
+    if (pairs) { if (cls == 0) GS_SM(0, true); else if (cls == 1) GS_SM(1, true); else if (cls == 2 || GS_PAIR_CLASSES < 4) GS_SM(2, true); else GS_SM(3, true); }
     else { if (cls == 0) GS_SM(0, false); else if (cls == 1) GS_SM(1, false); else if (cls == 2) GS_SM(2, false); else GS_SM(3, false); }
 #undef GS_SM
     return (int)hipGetLastError();

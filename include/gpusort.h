@@ -153,7 +153,7 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes,
  * on bits [begin_bit, end_bit); segments must not overlap, empty ones are fine, and positions
  * outside every segment are not written (offsets outside [0, num_items] are clamped on the device).  DoubleBuffer semantics as gs_lsb_sort_u32 (both
  * halves may be clobbered, the result is d_keys[*selector] after the call).  num_items < 2^31.
- * Segments that fit one workgroup (<= 17408 keys, 9216 pairs) cost one read and one write; the
+ * Segments that fit one workgroup (<= 17408 keys or pairs) cost one read and one write; the
  * larger ones are partitioned together, one 8-bit digit per pass.                       */
 size_t gs_segmented_temp_bytes(uint64_t num_items, int has_values, uint32_t num_segments);
 int gs_segmented_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], uint32_t *d_vals[2],
