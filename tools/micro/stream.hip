@@ -1,0 +1,81 @@
+// Streaming ceilings of the box ("a measured hipMemcpyDtoD / stream-copy ceiling"): read-only,
+// write-only and copy kernels over 4 GiB with 16-byte accesses, plus hipMemcpyDtoD, best of 10 each.
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/micro/stream tools/micro/stream.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %d line %d\n", (int)e_, __LINE__); exit(2); } } while (0)
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void copy_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n16)
+{
+    const size_t base = ((size_t)blockIdx.x * UNROLL) * 256 + threadIdx.x;
+    uint4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) if (base + (size_t)u * 256 < n16) v[u] = in[base + (size_t)u * 256];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) if (base + (size_t)u * 256 < n16) out[base + (size_t)u * 256] = v[u];
+}
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void read_kernel(const uint4 *__restrict__ in, uint32_t *__restrict__ sink, size_t n16)
+{
+    const size_t base = ((size_t)blockIdx.x * UNROLL) * 256 + threadIdx.x;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+        if (base + (size_t)u * 256 < n16) {
+            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+            const v4u *pv = reinterpret_cast<const v4u *>(&in[base + (size_t)u * 256]);
+            const v4u w = NT ? __builtin_nontemporal_load(pv) : *pv;
+            const uint4 v = make_uint4(w.x, w.y, w.z, w.w);
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    if (acc == 0x12345678u) sink[0] = acc;       // practically never: keeps the loads alive
+}
+template <int UNROLL>
+__global__ __launch_bounds__(256) void write_kernel(uint4 *__restrict__ out, size_t n16)
+{
+    const size_t base = ((size_t)blockIdx.x * UNROLL) * 256 + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+        if (base + (size_t)u * 256 < n16) out[base + (size_t)u * 256] = make_uint4(1u, 2u, 3u, (uint32_t)base);
+}
+
+template <typename F> static float best_ms(F launch)
+{
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int i = 0; i < 12; ++i) {
+        CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (i >= 2 && ms < best) best = ms;
+    }
+    return best;
+}
+
+int main()
+{
+    const size_t bytes = 4ull << 30, n16 = bytes / 16;
+    uint4 *a, *b; uint32_t *sink;
+    CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&sink, 256));
+    CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 2, bytes));
+    constexpr int U = 4;
+    const unsigned grid = (unsigned)((n16 + 256 * U - 1) / (256 * U));
+    float t;
+    t = best_ms([&] { hipLaunchKernelGGL(copy_kernel<U>, dim3(grid), dim3(256), 0, 0, a, b, n16); });
+    printf("copy kernel   4 GiB -> 4 GiB: %.3f ms = %.2f TB/s (read + write)\n", t, 2.0 * bytes / t / 1e9);
+    t = best_ms([&] { hipLaunchKernelGGL((read_kernel<U, false>), dim3(grid), dim3(256), 0, 0, a, sink, n16); });
+    printf("read kernel   4 GiB         : %.3f ms = %.2f TB/s\n", t, 1.0 * bytes / t / 1e9);
+    t = best_ms([&] { hipLaunchKernelGGL((read_kernel<U, true>), dim3(grid), dim3(256), 0, 0, a, sink, n16); });
+    printf("read kernel   4 GiB (nt)    : %.3f ms = %.2f TB/s\n", t, 1.0 * bytes / t / 1e9);
+    t = best_ms([&] { hipLaunchKernelGGL(write_kernel<U>, dim3(grid), dim3(256), 0, 0, b, n16); });
+    printf("write kernel  4 GiB         : %.3f ms = %.2f TB/s\n", t, 1.0 * bytes / t / 1e9);
+    t = best_ms([&] { CK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0)); });
+    printf("hipMemcpyDtoD 4 GiB -> 4 GiB: %.3f ms = %.2f TB/s (read + write)\n", t, 2.0 * bytes / t / 1e9);
+    hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
+    printf("hipDeviceProp: %s, memoryClockRate %d kHz, memoryBusWidth %d bit -> x2 (DDR) = %.2f TB/s; clockRate %d kHz, %d CUs, L2 %d B\n",
+           p.gcnArchName, p.memoryClockRate, p.memoryBusWidth, 2.0 * p.memoryClockRate * 1e3 * p.memoryBusWidth / 8 / 1e12,
+           p.clockRate, p.multiProcessorCount, p.l2CacheSize);
+    return 0;
+}
