@@ -7,15 +7,23 @@
 #include <cstdlib>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %d line %d\n", (int)e_, __LINE__); exit(2); } } while (0)
 
-template <int UNROLL>
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+template <int UNROLL, bool NTL = false, bool NTS = false>
 __global__ __launch_bounds__(256) void copy_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n16)
 {
     const size_t base = ((size_t)blockIdx.x * UNROLL) * 256 + threadIdx.x;
-    uint4 v[UNROLL];
+    const v4u *pi = reinterpret_cast<const v4u *>(in);
+    v4u *po = reinterpret_cast<v4u *>(out);
+    v4u v[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) if (base + (size_t)u * 256 < n16) v[u] = in[base + (size_t)u * 256];
+    for (int u = 0; u < UNROLL; ++u)
+        if (base + (size_t)u * 256 < n16) v[u] = NTL ? __builtin_nontemporal_load(&pi[base + (size_t)u * 256]) : pi[base + (size_t)u * 256];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) if (base + (size_t)u * 256 < n16) out[base + (size_t)u * 256] = v[u];
+    for (int u = 0; u < UNROLL; ++u)
+        if (base + (size_t)u * 256 < n16) {
+            if (NTS) __builtin_nontemporal_store(v[u], &po[base + (size_t)u * 256]);
+            else po[base + (size_t)u * 256] = v[u];
+        }
 }
 template <int UNROLL, bool NT>
 __global__ __launch_bounds__(256) void read_kernel(const uint4 *__restrict__ in, uint32_t *__restrict__ sink, size_t n16)
@@ -25,7 +33,6 @@ __global__ __launch_bounds__(256) void read_kernel(const uint4 *__restrict__ in,
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u)
         if (base + (size_t)u * 256 < n16) {
-            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
             const v4u *pv = reinterpret_cast<const v4u *>(&in[base + (size_t)u * 256]);
             const v4u w = NT ? __builtin_nontemporal_load(pv) : *pv;
             const uint4 v = make_uint4(w.x, w.y, w.z, w.w);
@@ -65,6 +72,10 @@ int main()
     float t;
     t = best_ms([&] { hipLaunchKernelGGL(copy_kernel<U>, dim3(grid), dim3(256), 0, 0, a, b, n16); });
     printf("copy kernel   4 GiB -> 4 GiB: %.3f ms = %.2f TB/s (read + write)\n", t, 2.0 * bytes / t / 1e9);
+    t = best_ms([&] { hipLaunchKernelGGL((copy_kernel<U, true, false>), dim3(grid), dim3(256), 0, 0, a, b, n16); });
+    printf("copy kernel, nt loads       : %.3f ms = %.2f TB/s (read + write)\n", t, 2.0 * bytes / t / 1e9);
+    t = best_ms([&] { hipLaunchKernelGGL((copy_kernel<U, true, true>), dim3(grid), dim3(256), 0, 0, a, b, n16); });
+    printf("copy kernel, nt loads+stores: %.3f ms = %.2f TB/s (read + write)\n", t, 2.0 * bytes / t / 1e9);
     t = best_ms([&] { hipLaunchKernelGGL((read_kernel<U, false>), dim3(grid), dim3(256), 0, 0, a, sink, n16); });
     printf("read kernel   4 GiB         : %.3f ms = %.2f TB/s\n", t, 1.0 * bytes / t / 1e9);
     t = best_ms([&] { hipLaunchKernelGGL((read_kernel<U, true>), dim3(grid), dim3(256), 0, 0, a, sink, n16); });
