@@ -6,6 +6,13 @@ does not export a declared symbol, importing this module raises.
 import ctypes as C
 import os
 
+# torch BEFORE the library: the ROCm wheel of torch carries its own HIP runtime (torch/lib/libamdhip64.so) and loads
+# it into the global symbol scope; libgpusort.so, loaded afterwards, then binds its HIP calls to that same runtime,
+# which is what makes torch's streams, graphs and allocations meaningful to it.  Loaded first, the library would bind
+# to /opt/rocm's copy instead: a second runtime in the process, which finds no device once torch's owns it
+# (every call fails with hipError 100).  tests/test_concurrency_gpu.py and tests/test_abi.py pin this.
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GS_LIB_PATH", os.path.join(_HERE, "lib", "libgpusort.so"))   # override: experiments only
 CSRC_DIR = os.path.join(_HERE, "csrc")

@@ -21,6 +21,11 @@ struct gs_profile {
     uint64_t launches[GS_K_COUNT] = {0};
 };
 
+// Entry points report launch failures through hipGetLastError(), which is per host thread and also holds whatever
+// an EARLIER HIP call of the caller (another library, the framework) left behind: drop that first, so that only
+// this call's own errors are reported.
+#define GS_CLEAR_STALE_ERROR() ((void)hipGetLastError())
+
 namespace gs {
 extern thread_local gs_profile *tl_profile;
 

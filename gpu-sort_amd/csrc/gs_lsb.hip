@@ -820,6 +820,7 @@ extern "C" {
 #ifdef GS_EXP_PHASES
 int gs_exp_phases(uint32_t *host_out, uint32_t blocks)
 {
+    GS_CLEAR_STALE_ERROR();
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(gs_phase_buf), (size_t)blocks * 16 * sizeof(uint32_t));
 }
 #endif
@@ -839,6 +840,7 @@ void gs_lsb_geometry(uint64_t num_items, int /*has_values*/, uint32_t *grid, uin
 int gs_lsb_upsweep_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys_in, uint64_t num_items, int shift,
                        int bits, int descending, int key_type_in, void *stream)
 {
+    GS_CLEAR_STALE_ERROR();
     if (num_items >= (1ull << 32) || bits < 1 || bits > 8 || shift < 0 || shift + bits > 32) return hipErrorInvalidValue;
     if (!d_temp || temp_bytes < gs_lsb_temp_bytes(num_items, 0)) return hipErrorInvalidValue;
     if (num_items == 0) return hipSuccess;
@@ -850,6 +852,7 @@ int gs_lsb_upsweep_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys_i
 
 int gs_lsb_scan_spine(void *d_temp, size_t temp_bytes, uint64_t num_items, void *stream)
 {
+    GS_CLEAR_STALE_ERROR();
     if (num_items >= (1ull << 32)) return hipErrorInvalidValue;
     if (!d_temp || temp_bytes < gs_lsb_temp_bytes(num_items, 0)) return hipErrorInvalidValue;
     if (num_items == 0) return hipSuccess;
@@ -861,6 +864,7 @@ int gs_lsb_downsweep_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys
                          const uint32_t *d_vals_in, uint32_t *d_vals_out, uint64_t num_items, int shift, int bits,
                          int descending, int key_type_in, int key_type_out, void *stream)
 {
+    GS_CLEAR_STALE_ERROR();
     if (num_items >= (1ull << 32) || bits < 1 || bits > 8 || shift < 0 || shift + bits > 32) return hipErrorInvalidValue;
     if ((d_vals_in == nullptr) != (d_vals_out == nullptr)) return hipErrorInvalidValue;
     if (!d_temp || temp_bytes < gs_lsb_temp_bytes(num_items, 0)) return hipErrorInvalidValue;
@@ -879,6 +883,7 @@ int gs_lsb_downsweep_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys
 int gs_lsb_workspace_layout(void *d_temp, uint64_t num_items, uint32_t **d_spine, uint32_t **d_totals,
                             uint16_t **d_prefix16)
 {
+    GS_CLEAR_STALE_ERROR();
     const LsbWorkspace ws = lsb_carve(d_temp, num_items);
     if (d_spine) *d_spine = ws.spine;
     if (d_totals) *d_totals = ws.totals;
@@ -889,6 +894,7 @@ int gs_lsb_workspace_layout(void *d_temp, uint64_t num_items, uint32_t **d_spine
 int gs_lsb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], uint32_t *d_vals[2], int *selector,
                     uint64_t num_items, int begin_bit, int end_bit, int descending, int key_type, void *stream)
 {
+    GS_CLEAR_STALE_ERROR();
     if (!selector || (*selector != 0 && *selector != 1) || !d_keys) return hipErrorInvalidValue;
     if (begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) return hipErrorInvalidValue;
     if (num_items >= (1ull << 32)) return hipErrorInvalidValue;
@@ -936,6 +942,7 @@ int gs_lsb_sort_copy_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys
                          const uint32_t *d_vals_in, uint32_t *d_vals_out, uint64_t num_items, int begin_bit, int end_bit,
                          int descending, int key_type, void *stream)
 {
+    GS_CLEAR_STALE_ERROR();
     if (begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) return hipErrorInvalidValue;
     if (num_items >= (1ull << 32)) return hipErrorInvalidValue;
     if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;

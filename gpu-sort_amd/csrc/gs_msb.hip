@@ -1254,6 +1254,7 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
                     uint32_t *d_keys_alt, uint32_t *d_vals_alt, uint32_t **d_sorted_keys, uint32_t **d_sorted_vals,
                     int key_type, void *stream, int synchronize)
 {
+    GS_CLEAR_STALE_ERROR();
     if (num_items >= (1ull << 32)) return hipErrorInvalidValue;
     if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;
     if (d_sorted_keys) *d_sorted_keys = d_keys;       // 32-bit keys: result in the input arrays
@@ -1365,6 +1366,7 @@ int gs_msb_first_pass_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_key
                           const uint32_t *d_vals_in, uint32_t *d_vals_out, uint64_t num_items, int key_type,
                           uint64_t *d_bucket_counts, void *stream)
 {
+    GS_CLEAR_STALE_ERROR();
     if (num_items >= (1ull << 32) || !d_bucket_counts) return hipErrorInvalidValue;
     if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
@@ -1393,6 +1395,7 @@ int gs_msb_finish_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_
                       uint32_t *d_vals_out, uint64_t num_items, const uint64_t *h_piece_counts, int num_src, int key_type,
                       void *stream, int synchronize)
 {
+    GS_CLEAR_STALE_ERROR();
     if (num_items >= (1ull << 32) || num_src < 1 || num_src > RADIX || !h_piece_counts) return hipErrorInvalidValue;
     if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;
     // bucket b = all pieces (s, b); the buffer holds source 0's pieces in byte order, then source 1's, ...
@@ -1475,6 +1478,7 @@ int gs_segmented_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], 
                           uint64_t num_items, uint32_t num_segments, const int32_t *d_begin_offsets,
                           const int32_t *d_end_offsets, int begin_bit, int end_bit, int descending, int key_type, void *stream)
 {
+    GS_CLEAR_STALE_ERROR();
     if (!selector || (*selector != 0 && *selector != 1) || !d_keys) return hipErrorInvalidValue;
     if (begin_bit < 0 || end_bit > 32 || begin_bit > end_bit) return hipErrorInvalidValue;
     if (num_items >= (1ull << 31)) return hipErrorInvalidValue;                  // int offsets
@@ -1540,6 +1544,7 @@ int gs_segmented_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], 
 int gs_shard_histogram_u32(const uint32_t *d_keys, uint64_t num_items, int bits, uint64_t *d_hist, int key_type,
                            void *stream)
 {
+    GS_CLEAR_STALE_ERROR();
     if (bits < 1 || bits > SHARD_MAX_BITS || !d_hist) return hipErrorInvalidValue;
     if (key_type < GS_KEY_U32 || key_type > GS_KEY_F32) return hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
@@ -1566,6 +1571,7 @@ int gs_shard_partition_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_ke
                            const uint8_t *d_dest_of_bin, int num_ranks, const uint64_t *d_bin_hist, uint64_t *d_counts,
                            int key_type, void *stream)
 {
+    GS_CLEAR_STALE_ERROR();
     if (bits < 1 || bits > SHARD_MAX_BITS || num_ranks < 1 || num_ranks > RADIX || !d_dest_of_bin || !d_counts)
         return hipErrorInvalidValue;
     if (num_items >= (1ull << 32)) return hipErrorInvalidValue;

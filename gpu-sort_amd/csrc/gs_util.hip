@@ -166,6 +166,7 @@ void gs_profile_end(void) { tl_profile = nullptr; }
 
 int gs_profile_read(gs_profile *p, double total_ms[GS_K_COUNT], uint64_t launches[GS_K_COUNT])
 {
+    GS_CLEAR_STALE_ERROR();
     if (!p) return hipErrorInvalidValue;
     for (auto &sp : p->spans) {
         hipError_t e = hipEventSynchronize(sp.b);
@@ -198,6 +199,7 @@ const char *gs_error_string(int err) { return hipGetErrorString((hipError_t)err)
 int gs_generate_u32(uint32_t *d_out, uint64_t num_items, int kind, uint64_t seed, uint64_t start_index, int level,
                     void *stream)
 {
+    GS_CLEAR_STALE_ERROR();
     if (kind < GS_GEN_UNIFORM || kind > GS_GEN_ENUMERATED) return hipErrorInvalidValue;
     if (num_items == 0) return hipSuccess;
     const dim3 g(stream_grid(num_items)), b(256);
@@ -213,6 +215,7 @@ int gs_generate_u32(uint32_t *d_out, uint64_t num_items, int kind, uint64_t seed
 
 int gs_check_sorted_u32(const uint32_t *d_keys, uint64_t num_items, int descending, uint64_t *d_result, void *stream)
 {
+    GS_CLEAR_STALE_ERROR();
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = zero_async(d_result, 3 * sizeof(uint64_t), s);
     if (e != hipSuccess) return (int)e;
@@ -225,6 +228,7 @@ int gs_check_sorted_u32(const uint32_t *d_keys, uint64_t num_items, int descendi
 int gs_check_pairs_enumerated_u32(const uint32_t *d_keys_in, const uint32_t *d_keys_sorted, const uint32_t *d_vals,
                                   uint64_t num_items, uint64_t *d_result, void *stream)
 {
+    GS_CLEAR_STALE_ERROR();
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = zero_async(d_result, 2 * sizeof(uint64_t), s);
     if (e != hipSuccess) return (int)e;

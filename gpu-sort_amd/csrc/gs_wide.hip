@@ -291,6 +291,7 @@ size_t gs_lsb_wide_temp_bytes(uint64_t num_items, int /*key_bytes*/, int /*val_b
 int gs_lsb_sort_wide(void *d_temp, size_t temp_bytes, void *d_keys[2], void *d_vals[2], int *selector, uint64_t num_items,
                      int key_bytes, int val_bytes, int begin_bit, int end_bit, int descending, int key_type, void *stream)
 {
+    GS_CLEAR_STALE_ERROR();
     if (!selector || (*selector != 0 && *selector != 1) || !d_keys) return hipErrorInvalidValue;
     if (key_bytes != 4 && key_bytes != 8) return hipErrorInvalidValue;
     if (val_bytes != 0 && val_bytes != 4 && val_bytes != 8) return hipErrorInvalidValue;

@@ -70,3 +70,26 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("import must fail when libgpusort.so is absent")
+
+
+def test_package_import_brings_torch_in_before_the_library():
+    """The HIP runtime the library binds to is decided when it is loaded: torch's bundled runtime must already be in
+    the global symbol scope (see gpu-sort_amd/_lib.py).  A fresh interpreter that imports only the package must
+    therefore find torch loaded before libgpusort.so."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, ctypes; sys.path.insert(0, %r)\n"
+        "orig = ctypes.CDLL.__init__\n"
+        "def spy(self, name, *a, **k):\n"
+        "    if name and 'libgpusort' in str(name):\n"
+        "        t = sys.modules.get('torch')\n"
+        "        print('torch fully imported at load:', t is not None and hasattr(t, 'cuda') and hasattr(t, 'Tensor'))\n"
+        "    orig(self, name, *a, **k)\n"
+        "ctypes.CDLL.__init__ = spy\n"
+        "import gpu_sort_amd\n"
+        "print('order ok')\n"
+    ) % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "order ok" in out.stdout, out.stderr[-2000:]
+    assert "torch fully imported at load: True" in out.stdout, out.stdout
