@@ -1042,8 +1042,9 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
         if (HAS_VALUES) {
             for (uint32_t j = tid; j < T.size; j += THREADS) {
                 const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[j];
-                qk[j] = twiddle_out(kv.x, f32_out, xor_out);
-                qv[j] = kv.y;
+                // whole lines of final output, written once: streaming stores (+0.3...0.7 % on the whole sort)
+                __builtin_nontemporal_store(twiddle_out(kv.x, f32_out, xor_out), &qk[j]);
+                __builtin_nontemporal_store(kv.y, &qv[j]);
             }
         } else {
             const uint32_t t0 = fresh((uint32_t)tid);
@@ -1052,7 +1053,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t j = t0 + i * THREADS;
-                if (j < T.size) *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(qk) + j * 4u) = twiddle_out(pos[i], f32_out, xor_out);
+                if (j < T.size) __builtin_nontemporal_store(twiddle_out(pos[i], f32_out, xor_out), reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(qk) + j * 4u));
             }
         }
         }   // done
