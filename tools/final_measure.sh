@@ -1,6 +1,6 @@
 set -e
 export TMPDIR=/tmp
-O=gpurun_out/v8; mkdir -p $O
+O=gpurun_out/${GS_MEASURE_TAG:-v9}; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 echo bench-done
 python bench.py --pairs --no-cpu-baseline > $O/bench_pairs.json 2>> $O/bench.err
@@ -14,6 +14,7 @@ echo variants-done
 echo prof-lsb-done
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof_msb -- python3 $OLDPWD/bench.py --algo msb --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$O/profiled_bench_msb.json 2> $OLDPWD/$O/prof_msb.err)
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof_sh -- python3 $OLDPWD/bench.py --force-sharded --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$O/profiled_bench_sharded1.json 2> $OLDPWD/$O/prof_sh.err)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof_msbp -- python3 $OLDPWD/bench.py --algo msb --pairs --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$O/profiled_bench_msb_pairs.json 2> $OLDPWD/$O/prof_msbp.err)
 echo prof-done
 find $O -name "*kernel_trace.csv" -delete
 ls $O
