@@ -159,6 +159,72 @@ def wide_case(it):
         fail("wide values (stability)", **case)
 
 
+def shard_case(it):
+    """The multi-GPU pipeline's kernels with every rank emulated in this process: gs_msb_first_pass_u32 on W random
+    shards, the host's split / group maps, then for one random rank the receive buffer it would get (group-major,
+    source-major, pieces where the exchange would put them) and gs_msb_finish_u32 per group."""
+    from gpu_sort_amd import sharded
+    W = int(rng.integers(1, 9)); G = int(rng.integers(1, 5)); pairs = bool(rng.random() < 0.5)
+    sizes = [int(rng.choice([0, 1, 777, 8192, 50000, 200000, 400003])) for _ in range(W)]
+    kind = str(rng.choice(KINDS))
+    case = dict(it=it, algo="shard", W=W, G=G, pairs=pairs, sizes=sizes, kind=kind, seed=seed)
+    ops = sharded.DeviceOps(dev)
+    nmax = max(max(sizes), 1)
+    temp = torch.empty(ops.temp_bytes(sum(sizes) + 4096, pairs, W), dtype=torch.uint8, device=dev)
+    keys, vals, part_k, part_v, hist = [], [], [], [], []
+    base = 0
+    for n_s in sizes:
+        k = make_keys(n_s, kind) if n_s else torch.empty(0, dtype=torch.int32, device=dev)
+        v = (torch.arange(n_s, device=dev) + base).to(torch.int32)
+        base += n_s
+        pk, pv = ops.empty(n_s), (ops.empty(n_s) if pairs else None)
+        if n_s:
+            c = ops.first_pass(k, v if pairs else None, n_s, temp, pk, pv)
+            hist.append(c.cpu().numpy())
+        else:
+            hist.append(np.zeros(256, np.int64))
+        keys.append(k); vals.append(v); part_k.append(pk); part_v.append(pv)
+    hist_all = np.stack(hist).astype(np.int64)
+    if hist_all.sum() == 0:
+        return
+    dest, per_rank = sharded.compute_splits(hist_all, W)
+    grp = sharded.group_bins(hist_all, dest, W, G)
+    r = int(rng.integers(0, W))
+    m = int(per_rank[r])
+    if m == 0:
+        return
+    recv_k, out_k = ops.empty(m), ops.empty(m)
+    recv_v, out_v = (ops.empty(m), ops.empty(m)) if pairs else (None, None)
+    off = np.cumsum(hist_all, axis=1) - hist_all                     # offset of bin b in source s's grouped shard
+    o = 0
+    for g in range(G):
+        own = (dest == r) & (grp == g)
+        o0 = o
+        for sidx in range(W):
+            sel = np.nonzero(own)[0]
+            cnt = int(hist_all[sidx][own].sum())
+            if cnt:
+                first = sel[np.nonzero(hist_all[sidx][sel])[0][0]]
+                st = int(off[sidx][first])
+                recv_k[o:o + cnt] = part_k[sidx][st:st + cnt]
+                if pairs:
+                    recv_v[o:o + cnt] = part_v[sidx][st:st + cnt]
+                o += cnt
+        if o > o0:
+            pieces = np.where(own[None, :], hist_all, 0)
+            ops.finish(recv_k[o0:], recv_v[o0:] if pairs else None, o - o0, out_k[o0:], out_v[o0:] if pairs else None, pieces, temp)
+    allk = torch.cat(keys); allv = torch.cat(vals)
+    mine = torch.from_numpy(dest == r).to(dev)[(allk.to(torch.int64) >> 24) & 0xFF]
+    exp = torch.sort(allk[mine].to(torch.int64) & 0xFFFFFFFF)[0]
+    if not torch.equal(out_k[:m].to(torch.int64) & 0xFFFFFFFF, exp):
+        fail("sharded finish keys", **case)
+    if pairs:
+        got = ((out_k[:m].to(torch.int64) & 0xFFFFFFFF) << 32) | (out_v[:m].to(torch.int64) & 0xFFFFFFFF)
+        want = ((allk[mine].to(torch.int64) & 0xFFFFFFFF) << 32) | (allv[mine].to(torch.int64) & 0xFFFFFFFF)
+        if not torch.equal(torch.sort(got)[0], torch.sort(want)[0]):
+            fail("sharded finish values", **case)
+
+
 KINDS = ["uniform", "and1", "and3", "and6", "and10", "few", "const", "ones_heavy", "sorted", "reverse", "low_bytes", "hot"]
 counts = {}
 for it in range(iters):
@@ -166,6 +232,10 @@ for it in range(iters):
     if algo == "wide":
         counts[algo] = counts.get(algo, 0) + 1
         wide_case(it)
+        continue
+    if rng.random() < 0.08:
+        counts["shard"] = counts.get("shard", 0) + 1
+        shard_case(it)
         continue
     pairs = bool(rng.random() < 0.5)
     n = max(0, pick_n())
