@@ -44,8 +44,12 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=27)
     ap.add_argument("--verify", action="store_true", help="device-side sortedness + checksum on every step")
-    ap.add_argument("--exchange-groups", type=int, default=4,
-                    help="N>1: collectives the all-to-all is cut into (group g is finished while g+1.. are in flight)")
+    ap.add_argument("--exchange-groups", type=int, default=1,
+                    help="N>1: collectives the all-to-all is cut into (group g is finished while g+1.. are in flight); "
+                         "1 = exchange, then finish (the default: see ShardedSorter)")
+    ap.add_argument("--one-rank-rccl", action="store_true",
+                    help="with --force-sharded: a ONE-rank RCCL group, and the N>1 code path (size all_gather, grouped "
+                         "asynchronous all_to_all, one finish per group) run on it -- what a one-GPU box can show of it")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the bucket-sharded pipeline even on one rank (exercises the N>1 code path)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -98,6 +102,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world == 1 and args.one_rank_rccl:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse_on_one_gpu:
@@ -126,7 +134,8 @@ def main():
         from gpu_sort_amd import sharded
         # default: exchange after the first MSB digit pass; --algo lsb|msb: group-by-destination + full local sort
         runner = sharded.ShardedSorter(n, args.pairs, dev, local_algo=args.algo or "lsb",
-                                       pipeline="partition" if args.algo else "msb", groups=args.exchange_groups)
+                                       pipeline="partition" if args.algo else "msb", groups=args.exchange_groups,
+                                       force_exchange=args.one_rank_rccl)
         nbytes = 0
         temp = None
     elif algo == "lsb":
@@ -244,7 +253,7 @@ def main():
             "metric": "Gkeys/s sorting 2^30 uint32 keys; achieved HBM GB/s vs roofline",
             "value": round(value, 3), "unit": "Gkeys/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo)" if args.rehearse_on_one_gpu else ""),
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo)" if args.rehearse_on_one_gpu else "") + (" (one-rank RCCL group: the exchange is a device-local copy)" if args.one_rank_rccl else ""),
             "config": {"workload": (f"{algo}_radix_sort_2^{args.log2n}_u32_{args.dist}_"
                                     f"{'pairs' if args.pairs else 'keys_only'}" + ("_per_gpu_sharded" if sharded_path else "")),
                        "keys_per_gpu": n, "has_values": args.pairs,
@@ -259,7 +268,7 @@ def main():
         if verified is not None:
             line["verified"] = bool(verified)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.one_rank_rccl:
         dist.destroy_process_group()
 
 

@@ -32,6 +32,10 @@ import torch
 import torch.distributed as dist
 
 SHARD_BITS = 12
+# Largest single send/recv handed to the collective library, in 4-byte elements (512 MiB).  Measured on the MI355X box
+# (ROCm 7.2 RCCL under torch 2.10): a rank's send to ITSELF silently delivers only the first half of a message of 2 GiB
+# or more (tools/rccl_selfcopy.py); 1 GiB is still whole.  Bigger messages are cut into rounds below this size.
+MAX_MSG = 1 << 27
 
 
 def compute_splits(hist_all, world):
@@ -154,9 +158,24 @@ class DeviceOps:
         return check_sorted(keys, count) if count else (0, 0, 0)
 
 
-def _all_to_all(out, inp, recv_counts, send_counts, group):
+def _all_to_all(out, inp, recv_counts, send_counts, group, bound=None):
     """The one exchange.  RCCL moves device buffers directly; under the gloo backend (CPU tests, or two test
-    ranks sharing one GPU) device buffers are staged through host memory, because gloo has no device all-to-all."""
+    ranks sharing one GPU) device buffers are staged through host memory, because gloo has no device all-to-all.
+    bound: an upper bound on ANY rank's largest message that every rank knows (the shard size); when it exceeds
+    MAX_MSG the exchange goes out in ceil(bound / MAX_MSG) rounds of the list form, each message cut at multiples of
+    MAX_MSG (sender and receiver cut the same message at the same places)."""
+    big = max(max(recv_counts, default=0), max(send_counts, default=0)) if bound is None else bound
+    if big > MAX_MSG:
+        rounds = -(-int(big) // MAX_MSG)
+        so = np.concatenate(([0], np.cumsum(send_counts))).astype(np.int64)
+        ro = np.concatenate(([0], np.cumsum(recv_counts))).astype(np.int64)
+        for q in range(rounds):
+            ins = [inp[int(so[r]) + min(q * MAX_MSG, c):int(so[r]) + min((q + 1) * MAX_MSG, c)] for r, c in enumerate(send_counts)]
+            outs = [out[int(ro[r]) + min(q * MAX_MSG, c):int(ro[r]) + min((q + 1) * MAX_MSG, c)] for r, c in enumerate(recv_counts)]
+            h = _all_to_all_lists(outs, ins, group)
+            if h is not None:
+                h.wait()
+        return
     if inp.is_cuda and dist.get_backend(group) == "gloo":
         h_out = torch.empty(out.numel(), dtype=out.dtype)
         dist.all_to_all_single(h_out, inp.cpu(), recv_counts, send_counts, group=group)
@@ -193,14 +212,21 @@ class ShardedSorter:
     """Sorts a key array that is sharded over the ranks of the default process group."""
 
     def __init__(self, keys_per_rank, pairs, device, ops=None, local_algo="lsb", slack=1.25, group=None, pipeline="msb",
-                 max_imbalance=1.2, groups=4):
+                 max_imbalance=1.2, groups=1, force_exchange=False):
         """pipeline: "msb" (exchange after the first digit pass, falls back when 256 buckets leave a rank with
         more than max_imbalance x its fair share) or "partition" (12-bit group-by-destination + full local sort,
         local_algo = "lsb" | "msb").  groups: collectives the exchange of the "msb" pipeline is cut into (the
-        finish of one group overlaps the transfer of the next; 1 = one collective, no overlap)."""
+        finish of one group is enqueued behind its own collective only, so it can run while the next groups are
+        still in flight).  Default 1 = one exchange, then one finish: on the one-GPU box, where a one-rank RCCL
+        group turns the exchange into a device-local copy, the overlapped form is SLOWER (21.9 ms against 14.4 ms
+        per 2^30 keys: copy and finish kernels fight for HBM and the collective's kernels run 3x longer), and
+        whether xGMI transfers overlap better could not be measured there."""
         self.n, self.pairs, self.device, self.group = keys_per_rank, pairs, device, group
         self.pipeline, self.max_imbalance, self.groups = pipeline, max_imbalance, max(1, int(groups))
         self.stage_times = None        # set to {} to get host-synchronised stage times of the next "msb" sort
+        # tests: go through the collectives even with one rank (a one-rank RCCL group on the one-GPU box exercises
+        # the N > 1 code path -- list all_to_all, async work handles, stream waits -- on the real backend)
+        self.force_exchange = bool(force_exchange) and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.ops = ops if ops is not None else DeviceOps(device)
@@ -243,9 +269,9 @@ class ShardedSorter:
             self._alloc(int(m * 1.1) + 4096)
         self.ops.partition(keys, vals, n, SHARD_BITS, dest, world, self.temp, self.part_k, self.part_v, bin_hist=hist)
         if world > 1:
-            _all_to_all(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), self.group)
+            _all_to_all(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), self.group, bound=n)
             if self.pairs:
-                _all_to_all(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), self.group)
+                _all_to_all(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), self.group, bound=n)
             rk, rv = self.recv_k, self.recv_v
         else:
             rk, rv = self.part_k, self.part_v
@@ -257,7 +283,7 @@ class ShardedSorter:
         return sk, sv, m
 
     def _gather_counts(self, counts):
-        if self.world > 1:
+        if self.world > 1 or self.force_exchange:
             gathered = torch.empty(self.world * counts.numel(), dtype=counts.dtype, device=counts.device)
             _all_gather(gathered, counts, self.group)
             return gathered.cpu().numpy().reshape(self.world, -1)
@@ -285,7 +311,7 @@ class ShardedSorter:
         if timed:
             self._sync()
             t1 = time.perf_counter()
-        if world == 1:
+        if world == 1 and not self.force_exchange:
             pieces = np.where(dest[None, :] == rank, hist_all, 0)
             self.ops.finish(self.part_k, self.part_v, m, self.alt_k, self.alt_v, pieces, self.temp)
             if timed:
@@ -305,37 +331,45 @@ class ShardedSorter:
         goff = np.concatenate(([0], np.cumsum(m_g))).astype(np.int64)
         works = []
         for g in range(G):
-            ins_k, outs_k, ins_v, outs_v = [], [], [], []
-            o = int(goff[g])
-            for r in range(world):
-                sel = np.nonzero((dest == r) & (grp == g))[0]
-                start = int(my_off[sel[0]]) if sel.size else 0
-                cnt = int(mine[sel].sum()) if sel.size else 0
-                c = int(recv_g[g][r])
-                ins_k.append(self.part_k[start:start + cnt])
-                outs_k.append(self.recv_k[o:o + c])
-                if self.pairs:
-                    ins_v.append(self.part_v[start:start + cnt])
-                    outs_v.append(self.recv_v[o:o + c])
-                o += c
             if G == 1:
                 # one collective: the slices are adjacent in rank order, so the plain all_to_all_single does it
-                _all_to_all(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), self.group)
+                # (in rounds when a message could exceed MAX_MSG)
+                _all_to_all(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), self.group, bound=n)
                 if self.pairs:
-                    _all_to_all(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), self.group)
+                    _all_to_all(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), self.group, bound=n)
                 works.append([])
                 break
-            try:
-                w = [_all_to_all_lists(outs_k, ins_k, self.group)]
-            except (RuntimeError, NotImplementedError):
-                if g != 0:
-                    raise
-                # a backend without the list form of all_to_all (argument checking fails before anything is
-                # enqueued, and on every rank alike): one collective from now on
-                self.groups = 1
-                return self._sort_msb(keys, vals)
-            if self.pairs:
-                w.append(_all_to_all_lists(outs_v, ins_v, self.group))
+            # the largest (source, destination) message of this group, known to every rank from the gathered sizes
+            biggest = max(int(hist_all[src][(dest == r) & (grp == g)].sum()) for src in range(world) for r in range(world))
+            rounds = max(1, -(-biggest // MAX_MSG))
+            w = []
+            for q in range(rounds):
+                ins_k, outs_k, ins_v, outs_v = [], [], [], []
+                o = int(goff[g])
+                for r in range(world):
+                    sel = np.nonzero((dest == r) & (grp == g))[0]
+                    start = int(my_off[sel[0]]) if sel.size else 0
+                    cnt = int(mine[sel].sum()) if sel.size else 0
+                    c = int(recv_g[g][r])
+                    s0, s1 = min(q * MAX_MSG, cnt), min((q + 1) * MAX_MSG, cnt)        # my message to r, cut at MAX_MSG
+                    r0, r1 = min(q * MAX_MSG, c), min((q + 1) * MAX_MSG, c)            # r's message to me, same cuts
+                    ins_k.append(self.part_k[start + s0:start + s1])
+                    outs_k.append(self.recv_k[o + r0:o + r1])
+                    if self.pairs:
+                        ins_v.append(self.part_v[start + s0:start + s1])
+                        outs_v.append(self.recv_v[o + r0:o + r1])
+                    o += c
+                try:
+                    w.append(_all_to_all_lists(outs_k, ins_k, self.group))
+                except (RuntimeError, NotImplementedError):
+                    if g != 0 or q != 0:
+                        raise
+                    # a backend without the list form of all_to_all (argument checking fails before anything is
+                    # enqueued, and on every rank alike): one collective from now on
+                    self.groups = 1
+                    return self._sort_msb(keys, vals)
+                if self.pairs:
+                    w.append(_all_to_all_lists(outs_v, ins_v, self.group))
             works.append(w)
         if timed:
             for w in works:

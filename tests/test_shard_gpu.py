@@ -210,3 +210,45 @@ def test_multi_rank_on_one_gpu_over_gloo(tmp_path, cuda, oracle, world, dist_kin
         gv = np.concatenate([np.load(tmp_path / f"v{r}.npy") for r in range(world)])
         assert oracle.msb_check_pairs_enumerated(all_keys, got, gv) == 0
     assert {open(tmp_path / f"p{r}.txt").read() for r in range(world)} == {pipeline}
+
+
+def test_exchange_path_on_real_rccl_with_one_rank(tmp_path, cuda):
+    """The one-GPU box cannot run two RCCL ranks, but a ONE-rank RCCL group runs the N > 1 code path as it is: the
+    size all_gather, the list-form all_to_all issued as 4 asynchronous collectives on RCCL's stream, the compute
+    stream waiting on each work handle, one finish per group -- keys and pairs, verified by the global properties."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "%d")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+import gpu_sort_amd as gs
+from gpu_sort_amd import sharded
+dev = torch.device("cuda:0")
+n = 3000017
+for pairs in (False, True):
+    for groups in (4, 1):
+        srt = sharded.ShardedSorter(n, pairs, dev, groups=groups, force_exchange=True)
+        for seed in (1, 2):
+            keys = gs.generate_uniform_keys(n, seed=seed, device=dev)
+            vals = gs.generate_enumerated_values(n, device=dev) if pairs else None
+            chk = srt.input_checksum(keys)
+            sk, sv, cnt = srt.sort(keys, vals)
+            torch.cuda.synchronize()
+            ok, _ = srt.verify(sk, cnt, chk)
+            assert ok and cnt == n and srt.last["pipeline"] == "msb" and srt.last["groups"] == groups, (pairs, groups, srt.last)
+            if pairs:
+                assert gs.check_pairs_enumerated(keys, sk, sv, n)[0] == 0
+dist.destroy_process_group()
+print("rccl one-rank ok")
+'''
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code % (root, port)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "rccl one-rank ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

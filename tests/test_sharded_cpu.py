@@ -86,13 +86,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, dist_kind, pairs, out_dir, pipeline="msb", groups=4):
+def _worker(rank, world, port, n, dist_kind, pairs, out_dir, pipeline="msb", groups=4, max_msg=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gpu_sort_amd import sharded
     from oracle import oracle as O
+    if max_msg:
+        sharded.MAX_MSG = max_msg            # tiny messages: the multi-round paths of the exchange
     gen = {"uniform": O.gen_uniform, "zipf": O.gen_zipf}[dist_kind]
     keys = gen(n, 0, rank * n) if dist_kind != "const" else np.full(n, 7, np.uint32)
     vals = (O.gen_enumerated(n, rank * n)) if pairs else None
@@ -115,13 +117,17 @@ def _worker(rank, world, port, n, dist_kind, pairs, out_dir, pipeline="msb", gro
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dist_kind,pairs,pipeline,groups",
-                         [(2, "uniform", False, "msb", 4), (2, "zipf", True, "msb", 4), (4, "uniform", True, "msb", 3),
-                          (3, "uniform", False, "msb", 1), (2, "uniform", True, "msb", 200),     # more groups than buckets
-                          (2, "uniform", True, "partition", 4), (4, "zipf", False, "partition", 4)])
-def test_sharded_sort_over_gloo(tmp_path, oracle, world, dist_kind, pairs, pipeline, groups):
+@pytest.mark.parametrize("world,dist_kind,pairs,pipeline,groups,max_msg",
+                         [(2, "uniform", False, "msb", 4, None), (2, "zipf", True, "msb", 4, None),
+                          (4, "uniform", True, "msb", 3, None), (3, "uniform", False, "msb", 1, None),
+                          (2, "uniform", True, "msb", 200, None),     # more groups than buckets
+                          (2, "uniform", True, "partition", 4, None), (4, "zipf", False, "partition", 4, None),
+                          # messages capped at 1500 elements: every exchange goes out in several rounds
+                          (2, "uniform", True, "msb", 4, 1500), (3, "uniform", False, "msb", 1, 1500),
+                          (2, "zipf", True, "partition", 4, 1500)])
+def test_sharded_sort_over_gloo(tmp_path, oracle, world, dist_kind, pairs, pipeline, groups, max_msg):
     n = 50000
-    mp.spawn(_worker, args=(world, _free_port(), n, dist_kind, pairs, str(tmp_path), pipeline, groups), nprocs=world,
+    mp.spawn(_worker, args=(world, _free_port(), n, dist_kind, pairs, str(tmp_path), pipeline, groups, max_msg), nprocs=world,
              join=True)
     used = {open(tmp_path / f"p{r}.txt").read() for r in range(world)}
     assert len(used) == 1                                             # every rank took the same pipeline
