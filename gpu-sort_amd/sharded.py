@@ -77,6 +77,11 @@ def group_bins(hist_all, dest, world, groups):
     return grp
 
 
+def biggest_message(hist_all, dest, world):
+    """The largest (source, destination) message of the exchange, in elements: known to every rank alike."""
+    return max(int(hist_all[src][dest == r].sum()) for src in range(world) for r in range(world)) if hist_all.size else 0
+
+
 def exchange_plan(hist_all, dest, rank, world):
     """send_counts[r] = my keys going to rank r; recv_counts[r] = keys rank r sends to me."""
     send = np.array([int(hist_all[rank][dest == r].sum()) for r in range(world)], dtype=np.int64)
@@ -269,9 +274,9 @@ class ShardedSorter:
             self._alloc(int(m * 1.1) + 4096)
         self.ops.partition(keys, vals, n, SHARD_BITS, dest, world, self.temp, self.part_k, self.part_v, bin_hist=hist)
         if world > 1:
-            _all_to_all(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), self.group, bound=n)
+            _all_to_all(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), self.group, bound=biggest_message(hist_all, dest, world))
             if self.pairs:
-                _all_to_all(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), self.group, bound=n)
+                _all_to_all(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), self.group, bound=biggest_message(hist_all, dest, world))
             rk, rv = self.recv_k, self.recv_v
         else:
             rk, rv = self.part_k, self.part_v
@@ -334,9 +339,9 @@ class ShardedSorter:
             if G == 1:
                 # one collective: the slices are adjacent in rank order, so the plain all_to_all_single does it
                 # (in rounds when a message could exceed MAX_MSG)
-                _all_to_all(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), self.group, bound=n)
+                _all_to_all(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), self.group, bound=biggest_message(hist_all, dest, world))
                 if self.pairs:
-                    _all_to_all(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), self.group, bound=n)
+                    _all_to_all(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), self.group, bound=biggest_message(hist_all, dest, world))
                 works.append([])
                 break
             # the largest (source, destination) message of this group, known to every rank from the gathered sizes
