@@ -7,14 +7,13 @@ cut at its first digit ("msb" pipeline, the default):
   2. all ranks exchange the bucket sizes (all_gather, 2 KiB)            (torch.distributed)
   3. every rank computes the same monotone bucket -> rank map with balanced totals; a rank's
      share is then ONE contiguous slice of every grouped shard
-  4. one all-to-all with uneven splits moves every top-level bucket to its owner.  It is issued as
-     `groups` collectives, each carrying one run of the owner's buckets (about 1/groups of its keys),
-     all enqueued at once on RCCL's stream
+  4. one all-to-all with uneven splits moves every top-level bucket to its owner (no single message
+     above MAX_MSG: bigger ones go out in rounds)
   5. every rank finishes the MSB sort on the buckets it received, picking the pieces up where
      they lie (no regrouping pass)                                      (gs_msb_finish_u32)
-     -- group g is finished on the compute stream as soon as its collective is done, while the
-     collectives of groups g+1.. are still moving data over xGMI
-Rank r then holds the r-th slice of the globally sorted sequence.
+Rank r then holds the r-th slice of the globally sorted sequence.  Opt-in (`groups` > 1): the exchange
+as `groups` collectives, each carrying one run of every owner's buckets, all enqueued at once on RCCL's
+stream, and one finish per group enqueued behind its own collective only (see ShardedSorter).
 
 When 256 buckets cannot balance the ranks (a heavy top byte), the "partition" pipeline is used
 instead (decided identically on every rank from the gathered sizes): 4096-bin histogram of the
