@@ -260,7 +260,8 @@ class ShardedSorter:
             if out is not None:
                 return out
         hist = self.ops.histogram(keys, n, SHARD_BITS)
-        if world > 1:
+        exchange = world > 1 or self.force_exchange
+        if exchange:
             gathered = torch.empty(world * hist.numel(), dtype=hist.dtype, device=hist.device)
             _all_gather(gathered, hist, self.group)
             hist_all = gathered.cpu().numpy().reshape(world, -1)
@@ -272,7 +273,7 @@ class ShardedSorter:
         if m > self.cap:
             self._alloc(int(m * 1.1) + 4096)
         self.ops.partition(keys, vals, n, SHARD_BITS, dest, world, self.temp, self.part_k, self.part_v, bin_hist=hist)
-        if world > 1:
+        if exchange:
             _all_to_all(self.recv_k[:m], self.part_k[:n], recv.tolist(), send.tolist(), self.group, bound=biggest_message(hist_all, dest, world))
             if self.pairs:
                 _all_to_all(self.recv_v[:m], self.part_v[:n], recv.tolist(), send.tolist(), self.group, bound=biggest_message(hist_all, dest, world))
@@ -281,8 +282,8 @@ class ShardedSorter:
             rk, rv = self.part_k, self.part_v
             if m > rk.numel():
                 raise RuntimeError("internal: single-rank receive exceeds shard size")
-        sk, sv = self.ops.local_sort(rk, rv, m, self.alt_k if world > 1 else self.recv_k,
-                                     self.alt_v if world > 1 else self.recv_v, self.temp, self.local_algo)
+        sk, sv = self.ops.local_sort(rk, rv, m, self.alt_k if exchange else self.recv_k,
+                                     self.alt_v if exchange else self.recv_v, self.temp, self.local_algo)
         self.last = dict(count=m, send=send, recv=recv, per_rank=per_rank, dest=dest, pipeline="partition")
         return sk, sv, m
 

@@ -242,6 +242,17 @@ for pairs in (False, True):
             assert ok and cnt == n and srt.last["pipeline"] == "msb" and srt.last["groups"] == groups, (pairs, groups, srt.last)
             if pairs:
                 assert gs.check_pairs_enumerated(keys, sk, sv, n)[0] == 0
+for pairs, algo in ((False, "lsb"), (True, "msb")):      # the fallback pipeline through the same collectives
+    srt = sharded.ShardedSorter(n, pairs, dev, pipeline="partition", local_algo=algo, force_exchange=True)
+    keys = gs.generate_zipf_keys(n, seed=7, device=dev)
+    vals = gs.generate_enumerated_values(n, device=dev) if pairs else None
+    chk = srt.input_checksum(keys)
+    sk, sv, cnt = srt.sort(keys, vals)
+    torch.cuda.synchronize()
+    ok, _ = srt.verify(sk, cnt, chk)
+    assert ok and cnt == n and srt.last["pipeline"] == "partition", (pairs, algo, srt.last)
+    if pairs:
+        assert gs.check_pairs_enumerated(keys, sk, sv, n)[0] == 0
 dist.destroy_process_group()
 print("rccl one-rank ok")
 '''
