@@ -31,10 +31,11 @@ import torch
 import torch.distributed as dist
 
 SHARD_BITS = 12
-# Largest single send/recv handed to the collective library, in 4-byte elements (512 MiB).  Measured on the MI355X box
+# Largest single send/recv handed to the collective library, in 4-byte elements (768 MiB).  Measured on the MI355X box
 # (ROCm 7.2 RCCL under torch 2.10): a rank's send to ITSELF silently delivers only the first half of a message of 2 GiB
-# or more (tools/rccl_selfcopy.py); 1 GiB is still whole.  Bigger messages are cut into rounds below this size.
-MAX_MSG = 1 << 27
+# or more (tools/rccl_selfcopy.py); 1 GiB is still whole.  Bigger messages are cut into rounds below this size; the
+# 512 MiB messages of 8 ranks x 2^30 keys (a little more on some pairs, the buckets being what they are) stay whole.
+MAX_MSG = 3 << 26
 
 
 def compute_splits(hist_all, world):
