@@ -125,8 +125,7 @@ def _worker(rank, world, port, n, dist_kind, pairs, out_dir, pipeline="msb", gro
                           # messages capped at 1500 elements: every exchange goes out in several rounds
                           (2, "uniform", True, "msb", 4, 1500), (3, "uniform", False, "msb", 1, 1500),
                           (2, "zipf", True, "partition", 4, 1500)])
-def test_sharded_sort_over_gloo(tmp_path, oracle, world, dist_kind, pairs, pipeline, groups, max_msg):
-    n = 50000
+def test_sharded_sort_over_gloo(tmp_path, oracle, world, dist_kind, pairs, pipeline, groups, max_msg, n=50000):
     mp.spawn(_worker, args=(world, _free_port(), n, dist_kind, pairs, str(tmp_path), pipeline, groups, max_msg), nprocs=world,
              join=True)
     used = {open(tmp_path / f"p{r}.txt").read() for r in range(world)}
@@ -187,3 +186,9 @@ def test_compute_splits_properties():
         assert np.array_equal(tot_send, per_rank)
     dest, per_rank = compute_splits(np.zeros((2, 16), np.int64), 2)   # empty input
     assert per_rank.sum() == 0
+
+
+@pytest.mark.parametrize("n,world,pipeline,groups", [(1, 2, "msb", 1), (3, 3, "msb", 4), (7, 2, "partition", 1)])
+def test_tiny_shards(tmp_path, oracle, n, world, pipeline, groups):
+    """a handful of keys per rank: most ranks receive nothing, most buckets and groups are empty"""
+    test_sharded_sort_over_gloo(tmp_path, oracle, world, "zipf", True, pipeline, groups, None, n=n)
