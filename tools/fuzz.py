@@ -17,7 +17,12 @@ EDGES = [0, 1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4607, 4608, 4609,
          1 << 18, (1 << 20) + 3, 8192 * 2048, 8192 * 2048 + 1, (1 << 22) + 12345]
 
 
+BIG = os.environ.get("FUZZ_BIG") == "1"      # few iterations, sizes up to 2^28 + (32-bit byte offsets, many tiles)
+
+
 def pick_n():
+    if BIG:
+        return int(rng.choice([1 << 26, (1 << 27) + 12345, (1 << 28) + 7, 200_000_003, 100_000_000 + int(rng.integers(0, 9000))]))
     r = rng.random()
     if r < 0.35:
         return int(rng.choice(EDGES)) + int(rng.integers(-3, 4)) * int(rng.random() < 0.3)
