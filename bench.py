@@ -44,9 +44,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=27)
     ap.add_argument("--verify", action="store_true", help="device-side sortedness + checksum on every step")
-    ap.add_argument("--exchange-groups", type=int, default=1,
+    ap.add_argument("--exchange-groups", type=int, default=0,
                     help="N>1: collectives the all-to-all is cut into (group g is finished while g+1.. are in flight); "
-                         "1 = exchange, then finish (the default: see ShardedSorter)")
+                         "1 = exchange, then finish; 0 (default) = probe 1 and 4 during the warm-up (two untimed sorts "
+                         "each, max over ranks) and run the timed steps with the faster one")
     ap.add_argument("--one-rank-rccl", action="store_true",
                     help="with --force-sharded: a ONE-rank RCCL group, and the N>1 code path (size all_gather, grouped "
                          "asynchronous all_to_all, one finish per group) run on it -- what a one-GPU box can show of it")
@@ -134,7 +135,7 @@ def main():
         from gpu_sort_amd import sharded
         # default: exchange after the first MSB digit pass; --algo lsb|msb: group-by-destination + full local sort
         runner = sharded.ShardedSorter(n, args.pairs, dev, local_algo=args.algo or "lsb",
-                                       pipeline="partition" if args.algo else "msb", groups=args.exchange_groups,
+                                       pipeline="partition" if args.algo else "msb", groups=max(1, args.exchange_groups),
                                        force_exchange=args.one_rank_rccl)
         nbytes = 0
         temp = None
@@ -182,6 +183,27 @@ def main():
     for i in range(warmup):
         one_step(i)
     barrier()
+    # N > 1 (or the one-rank RCCL group): whether finishing group g while groups g+1.. are in flight pays depends on
+    # how the collective's kernels and ours share the GPU, which only the machine at hand can tell: probe both forms
+    # in the warm-up (identical decision on every rank: max over ranks of the probe times) and keep the faster one
+    probe = None
+    if sharded_path and not args.algo and args.exchange_groups == 0 and (world > 1 or args.one_rank_rccl):
+        probe = {}
+        for g in (1, 4):
+            runner.groups = g
+            runner.sort(inputs[0], vals[0] if args.pairs else None)       # settle (buffers, connections)
+            barrier()
+            tp = time.perf_counter()
+            for _ in range(2):
+                runner.sort(inputs[0], vals[0] if args.pairs else None)
+            barrier()
+            t = torch.tensor([(time.perf_counter() - tp) / 2 * 1e3], dtype=torch.float64,
+                             device="cpu" if args.rehearse_on_one_gpu else dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            probe[g] = round(float(t.item()), 3)
+        runner.groups = min(probe, key=probe.get)
+        barrier()
     prof = gs.KernelProfile()
     t0 = time.perf_counter()
     with prof:
@@ -258,6 +280,7 @@ def main():
                                     f"{'pairs' if args.pairs else 'keys_only'}" + ("_per_gpu_sharded" if sharded_path else "")),
                        "keys_per_gpu": n, "has_values": args.pairs,
                        **({"exchange_groups": groups_used} if sharded_path else {}),
+                       **({"exchange_groups_probe_ms": probe} if probe else {}),
                        "algorithm": ((f"shard_partition+local_{args.algo}" if args.algo else "msb_first_pass+all_to_all+msb_finish")
                                      if sharded_path else algo),
                        "distribution": args.dist, "parallelism": "single" if not sharded_path else f"msb_bucket_shard{world}"},
