@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--verify", action="store_true", help="device-side sortedness + checksum on every step")
     ap.add_argument("--exchange-groups", type=int, default=0,
                     help="N>1: collectives the all-to-all is cut into (group g is finished while g+1.. are in flight); "
-                         "1 = exchange, then finish; 0 (default) = probe 1 and 4 during the warm-up (two untimed sorts "
+                         "1 = exchange, then finish; 0 (default) = probe 1, 2 and 4 during the warm-up (two untimed sorts "
                          "each, max over ranks) and run the timed steps with the faster one")
     ap.add_argument("--one-rank-rccl", action="store_true",
                     help="with --force-sharded: a ONE-rank RCCL group, and the N>1 code path (size all_gather, grouped "
@@ -189,7 +189,7 @@ def main():
     probe = None
     if sharded_path and not args.algo and args.exchange_groups == 0 and (world > 1 or args.one_rank_rccl):
         probe = {}
-        for g in (1, 4):
+        for g in (1, 2, 4):
             runner.groups = g
             runner.sort(inputs[0], vals[0] if args.pairs else None)       # settle (buffers, connections)
             barrier()
