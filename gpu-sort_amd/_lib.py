@@ -36,6 +36,7 @@ SIGNATURES = {
     "gs_lsb_sort_wide": (i32, [vp, sz, pp, pp, C.POINTER(i32), u64, i32, i32, i32, i32, i32, i32, vp]),
     "gs_lsb_geometry": (None, [u64, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gs_lsb_workspace_layout": (i32, [vp, u64, pp, pp, pp]),
+    "gs_lsb_pipe_status": (i32, [vp, u64, C.POINTER(C.c_uint32), vp]),
     "gs_lsb_upsweep_u32": (i32, [vp, sz, vp, u64, i32, i32, i32, i32, vp]),
     "gs_lsb_scan_spine": (i32, [vp, sz, u64, vp]),
     "gs_lsb_downsweep_u32": (i32, [vp, sz, vp, vp, vp, vp, u64, i32, i32, i32, i32, i32, vp]),
@@ -58,7 +59,7 @@ SIGNATURES = {
     "gs_profile_read": (i32, [vp, C.POINTER(C.c_double), C.POINTER(u64)]),
     "gs_kernel_name": (C.c_char_p, [i32]),
 }
-GS_K_COUNT = 9
+GS_K_COUNT = 10
 
 
 class GpuSortError(RuntimeError):

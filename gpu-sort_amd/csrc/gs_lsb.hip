@@ -36,20 +36,40 @@ namespace gs {
 #ifndef UPSWEEP_SUB
 #define UPSWEEP_SUB 4      // histogram copies per wave (power of two)
 #endif
-// Plain dword loads in batches beat 16-byte loads here (0.81 vs 0.84 ms at 2^30) and need no alignment.
-__global__ __launch_bounds__(LSB_THREADS) void lsb_upsweep_kernel(const uint32_t *__restrict__ keys,
-                                                                  uint32_t *__restrict__ spine,
-                                                                  uint16_t *__restrict__ prefix16, PassParams p)
-{
+// relaxed agent-scope accesses = `sc1` loads / write-through stores: what workgroups of one launch may exchange
+// without fences (cdna_hip_programming.md Guideline 16, forms R1 / R2; compiler-visible, so hipcc counts their waits)
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t ld_agent(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// NEXT: the wave also counts the digit of the FOLLOWING pass (one plain histogram copy per wave) and the block adds
+// its sums to `next_totals` -- the pipelined pass needs the digit totals before its first tile is scattered.
+// PIPE: the block is one role of lsb_pipe_pass_kernel: key loads with the default cache policy (they must stay in the
+// Infinity Cache for the downsweep role; the streaming hint would keep them out), results published write-through.
+template <bool NEXT, bool PIPE>
+struct UpsweepSmem {
     // every wave counts into UPSWEEP_SUB copies of its histogram (lane & 3 picks one; rows padded by one word so
     // equal digits of different copies sit in different banks): under skew the lanes that share a hot digit
     // spread over four banks instead of queueing on one (Zipf keys: 1.40 -> ~1.0 ms at level 1 of the MSB sort)
-    __shared__ uint32_t hist[LSB_WAVES][UPSWEEP_SUB][RADIX + 1];
-    const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
-    uint32_t *my = hist[w][lane & (UPSWEEP_SUB - 1)];
-    for (int i = lane; i < UPSWEEP_SUB * (RADIX + 1); i += WAVE) (&hist[w][0][0])[i] = 0;
+    uint32_t hist[LSB_WAVES][UPSWEEP_SUB][RADIX + 1];
+    uint32_t hist2[NEXT ? LSB_WAVES : 1][NEXT ? RADIX : 1];
+    alignas(8) uint16_t pre[PIPE ? LSB_WAVES : 1][PIPE ? RADIX : 4];   // prefix16 rows on their way to 8-byte stores
+    alignas(8) uint32_t tot[PIPE ? RADIX : 2];
+};
 
-    const uint32_t chunk = blockIdx.x;
+// Plain dword loads in batches beat 16-byte loads here (0.81 vs 0.84 ms at 2^30) and need no alignment.
+template <bool NEXT, bool PIPE>
+__device__ __forceinline__ void upsweep_chunk(UpsweepSmem<NEXT, PIPE> &sm, const uint32_t *__restrict__ keys, uint32_t chunk,
+                                              uint32_t *__restrict__ spine, uint16_t *__restrict__ prefix16,
+                                              uint32_t *__restrict__ cc, uint32_t *__restrict__ next_totals, const PassParams &p,
+                                              const PipeParams &q)
+{
+    const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    uint32_t *my = sm.hist[w][lane & (UPSWEEP_SUB - 1)];
+    for (int i = lane; i < UPSWEEP_SUB * (RADIX + 1); i += WAVE) (&sm.hist[w][0][0])[i] = 0;
+    if (NEXT)
+        for (int i = lane; i < RADIX; i += WAVE) sm.hist2[w][i] = 0;
+
     const uint32_t tile = chunk * LSB_CHUNK + (uint32_t)w;
     if (tile < p.num_tiles) {
         const uint64_t lo = (uint64_t)tile * LSB_TILE;
@@ -58,6 +78,7 @@ __global__ __launch_bounds__(LSB_THREADS) void lsb_upsweep_kernel(const uint32_t
         auto count = [&](uint32_t raw) {
             const uint32_t k = twiddle_in(raw, p.f32_in, p.xor_in);
             hist_add(my, __builtin_amdgcn_ubfe(k, p.shift, p.bits));        // wave-private ds_add_u32
+            if (NEXT) hist_add(sm.hist2[w], __builtin_amdgcn_ubfe(k, q.next_shift, q.next_bits));
         };
         // batches of dword loads from clamped indices: one code path for full, partial and misaligned tiles
         // (measured as fast as an unclamped unrolled variant; a loop of one guarded load per trip would pay
@@ -70,7 +91,8 @@ __global__ __launch_bounds__(LSB_THREADS) void lsb_upsweep_kernel(const uint32_t
 #pragma unroll
             for (int u = 0; u < GB; ++u) {
                 const uint32_t idx = j + u * WAVE + lane;
-                v[u] = __builtin_nontemporal_load(&src[idx < last ? idx : last]);   // streaming hint: 0.80 -> 0.76 ms
+                const uint32_t *at = &src[idx < last ? idx : last];
+                v[u] = PIPE ? *at : __builtin_nontemporal_load(at);   // streaming hint: 0.80 -> 0.76 ms
             }
 #pragma unroll
             for (int u = 0; u < GB; ++u)
@@ -83,14 +105,47 @@ __global__ __launch_bounds__(LSB_THREADS) void lsb_upsweep_kernel(const uint32_t
 #pragma unroll
         for (int j = 0; j < LSB_WAVES; ++j) {
             const uint32_t t = chunk * LSB_CHUNK + (uint32_t)j;
-            if (t < p.num_tiles) prefix16[(size_t)t * RADIX + tid] = (uint16_t)run;
+            if (PIPE) sm.pre[j][tid] = (uint16_t)run;
+            else if (t < p.num_tiles) prefix16[(size_t)t * RADIX + tid] = (uint16_t)run;
             uint32_t c = 0;
 #pragma unroll
-            for (int q = 0; q < UPSWEEP_SUB; ++q) c += hist[j][q][tid];
+            for (int u = 0; u < UPSWEEP_SUB; ++u) c += sm.hist[j][u][tid];
             run += c;
         }
-        spine[(uint32_t)tid * p.grid + chunk] = run;
+        if (PIPE) sm.tot[tid] = run | (q.tag << 28);       // run <= 65536
+        else spine[(uint32_t)tid * p.grid + chunk] = run;
+        if (NEXT) {
+            uint32_t s2 = 0;
+#pragma unroll
+            for (int j = 0; j < LSB_WAVES; ++j) s2 += sm.hist2[j][tid];
+            if (s2) atomicAdd(&next_totals[tid], s2);
+        }
     }
+    if (PIPE) {
+        // publish: the chunk's prefix16 rows (wave w = tile w, 8 bytes per lane), drained by every storing wave,
+        // then -- behind the workgroup's barrier -- the tagged count words the scanner role polls
+        __syncthreads();
+        uint32_t tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));   // recomputed from scratch: otherwise `tile` lives (and spills) across the counting loop
+        const uint32_t tile2 = chunk * LSB_CHUNK + (tid2 >> 6);
+        if (tile2 < p.num_tiles)
+            st_agent(reinterpret_cast<uint64_t *>(prefix16 + (size_t)tile2 * RADIX) + lane,
+                     reinterpret_cast<const uint64_t *>(sm.pre[tile2 - chunk * LSB_CHUNK])[lane]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid < RADIX / 2)
+            st_agent(reinterpret_cast<uint64_t *>(cc + (size_t)chunk * RADIX) + tid, reinterpret_cast<const uint64_t *>(sm.tot)[tid]);
+    }
+}
+
+template <bool NEXT>
+__global__ __launch_bounds__(LSB_THREADS) void lsb_upsweep_kernel(const uint32_t *__restrict__ keys,
+                                                                  uint32_t *__restrict__ spine,
+                                                                  uint16_t *__restrict__ prefix16,
+                                                                  uint32_t *__restrict__ next_totals, PassParams p, PipeParams q)
+{
+    __shared__ UpsweepSmem<NEXT, false> sm;
+    upsweep_chunk<NEXT, false>(sm, keys, blockIdx.x, spine, prefix16, nullptr, next_totals, p, q);
 }
 
 // ---- small arrays (up to LSB_SMALL_TILES tiles): with one wave per tile a handful of waves would each
@@ -155,56 +210,6 @@ __global__ __launch_bounds__(RADIX) void lsb_scan_small_kernel(uint32_t *__restr
     const uint32_t ex = block_exclusive_scan_256(run, scratch, &total);
     if (c < grid) spine[(size_t)d * grid + c] = ex;
     if (c == 0) totals[d] = total;
-}
-
-// ------------------------------------------------- single-sweep histogram --
-// Digit totals of ALL passes in one read of the keys (single-sweep mode): the digit of
-// pass q is taken from the twiddled key, which is what the later passes see.
-struct Hist4Params {
-    uint32_t n;
-    int num_passes;
-    uint32_t shift[4], bits[4];
-    int f32_in;
-    uint32_t xor_in;
-};
-template <bool VEC>
-__global__ __launch_bounds__(LSB_THREADS) void lsb_hist4_kernel(const uint32_t *__restrict__ keys,
-                                                                uint32_t *__restrict__ totals4, Hist4Params hp)
-{
-    __shared__ uint32_t h[LSB_WAVES][4][RADIX];
-    const int tid = threadIdx.x, w = wave_id();
-    for (int i = tid; i < LSB_WAVES * 4 * RADIX; i += LSB_THREADS) (&h[0][0][0])[i] = 0;
-    __syncthreads();
-    auto count = [&](uint32_t raw) {
-        const uint32_t k = twiddle_in(raw, hp.f32_in, hp.xor_in);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q < hp.num_passes) hist_add(h[w][q], __builtin_amdgcn_ubfe(k, hp.shift[q], hp.bits[q]));
-    };
-    const uint32_t stride = gridDim.x * LSB_THREADS;
-    uint32_t done = 0;
-    if (VEC) {
-        const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
-        const uint32_t nvec = hp.n >> 2;
-        uint32_t v = blockIdx.x * LSB_THREADS + tid;
-        for (; v + 3u * stride < nvec && v + 3u * stride >= v; v += 4u * stride) {
-            const uint4 a = k4[v], b = k4[v + stride], c = k4[v + 2 * stride], d = k4[v + 3 * stride];
-            count(a.x); count(a.y); count(a.z); count(a.w);
-            count(b.x); count(b.y); count(b.z); count(b.w);
-            count(c.x); count(c.y); count(c.z); count(c.w);
-            count(d.x); count(d.y); count(d.z); count(d.w);
-        }
-        for (; v < nvec; v += stride) { const uint4 a = k4[v]; count(a.x); count(a.y); count(a.z); count(a.w); }
-        done = nvec << 2;
-    }
-    for (uint64_t i = (uint64_t)done + blockIdx.x * LSB_THREADS + tid; i < hp.n; i += stride) count(keys[i]);
-    __syncthreads();
-    for (int i = tid; i < 4 * RADIX; i += LSB_THREADS) {
-        uint32_t s = 0;
-#pragma unroll
-        for (int j = 0; j < LSB_WAVES; ++j) s += (&h[j][0][0])[i];
-        if (s) atomicAdd(&totals4[i], s);
-    }
 }
 
 // ------------------------------------------------------------------- scan --
@@ -296,21 +301,18 @@ __device__ uint32_t gs_phase_buf[131072 * 16];   // [block][phase], n <= 2^30
 // travel twiddled between passes), 1 = xor mask (signed keys, descending), 2 = float + xor.
 // BIG = false: n <= 2^30, so byte offsets into the output fit 32 bits and a store needs no
 // 64-bit address arithmetic.
-// FUSED = true (single-sweep mode, see the host section): no upsweep/scan ran for this pass;
-// the tile learns its global offsets by decoupled look-back over `status`, one 32-bit word
-// per (tile, digit): bits 31:30 = 0 empty / 1 tile count / 2 inclusive prefix, bits 29:0 the
-// value.  Each word is one self-validating granule written by one relaxed agent-scope store
-// and read by relaxed agent-scope loads (cdna_hip_programming.md Guideline 16, form R2).
-constexpr uint32_t ST_AGG = 1u << 30, ST_INC = 2u << 30, ST_VAL = (1u << 30) - 1u;
+// PIPE = true: the tile is one block of lsb_pipe_pass_kernel; its chunk's scanned counts come from the scanner
+// role as {tag, value} granules (`sc`), its in-chunk prefixes from the upsweep role (`prefix16`), both published
+// write-through inside the same launch and read here with agent-scope loads.
+constexpr uint32_t PIPE_SPIN_LIMIT = 1u << 18;   // polls (each >= one memory round trip) before a wait gives up
 
-template <bool HAS_VALUES, bool TAIL, int TW, bool BIG, bool FUSED = false>
-__global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep_kernel(
+template <bool HAS_VALUES, bool TAIL, int TW, bool BIG, bool PIPE>
+__device__ __forceinline__ void downsweep_tile(DownsweepSmem<HAS_VALUES> &sm, const uint32_t t,
     const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint16_t *__restrict__ prefix16,
-    const uint32_t *__restrict__ totals, PassParams p, uint32_t *__restrict__ status = nullptr,
-    uint32_t *__restrict__ error_word = nullptr)
+    const uint32_t *__restrict__ totals, const PassParams &p, const uint64_t *__restrict__ sc, uint32_t tag,
+    uint32_t *__restrict__ error_word)
 {
-    __shared__ __attribute__((aligned(16))) DownsweepSmem<HAS_VALUES> sm;
     constexpr bool ALLWAVE = HAS_VALUES;   // see step 3
 
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -326,9 +328,8 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
     const uint16_t *mybase = sm.wbase[w];
     const uint32_t wbase = (uint32_t)w * (WAVE * LSB_KPT) + lane;
     const uint32_t tail_valid = p.n - full_tiles * (uint32_t)LSB_TILE;   // used when TAIL
+    (void)full_tiles;
 
-    if (!TAIL && blockIdx.x >= full_tiles) return;
-    const uint32_t t = TAIL ? full_tiles : tile_of_item(blockIdx.x, full_tiles);
 #ifdef GS_EXP_PHASES
     unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
     const unsigned long long t0_ = tprev_, r0_ = __builtin_amdgcn_s_memrealtime();
@@ -338,6 +339,15 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
     if (!HAS_VALUES) __builtin_amdgcn_s_setprio(3);
     const uint64_t tile_base = (uint64_t)t * LSB_TILE;
     const uint32_t valid = TAIL ? tail_valid : (uint32_t)LSB_TILE;
+
+    // pipelined pass: the chunk's scanned counts are requested first, so they are back before the keys are
+    uint64_t scg[4] = {0, 0, 0, 0};
+    const uint64_t *scrow = nullptr;
+    if (PIPE && w == 0) {
+        scrow = sc + (size_t)(t / LSB_CHUNK) * RADIX + 4 * lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) scg[q] = ld_agent(scrow + q);
+    }
 
     // 1. wave-striped coalesced load
     uint32_t key[LSB_KPT], val[HAS_VALUES ? LSB_KPT : 1], pos[LSB_KPT];
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
 
     // this tile's global offsets (wave 0): scanned chunk count + count of the chunk's earlier tiles
     uint32_t tbase[4] = {0, 0, 0, 0};
-    if (!TAIL && !FUSED && w == 0) {
+    if (!TAIL && !PIPE && w == 0) {
         const uint32_t *sp = spine + (uint32_t)(4 * lane) * p.grid + t / LSB_CHUNK;
         const uint2 pf = reinterpret_cast<const uint2 *>(prefix16 + (size_t)t * RADIX)[lane];
         tbase[0] = sp[0] + (pf.x & 0xffffu);
@@ -393,54 +403,32 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
         tbase[3] = sp[3 * p.grid] + (pf.y >> 16);
     }
 
+    if (PIPE && !TAIL && w == 0) {
+        // every granule carries this pass's tag once the scanner has written it (normally long ago: the upsweep
+        // role runs PIPE_LEAD_CHUNKS ahead); only then may the prefix16 row be read (it was published before the
+        // counts the scanner waited for).  Bounded: a wait that gives up flags the sort instead of hanging the GPU.
+        uint32_t spins = 0;
+        for (;;) {
+            const bool ok = (uint32_t)(scg[0] >> 32) == tag && (uint32_t)(scg[1] >> 32) == tag &&
+                            (uint32_t)(scg[2] >> 32) == tag && (uint32_t)(scg[3] >> 32) == tag;
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+            if (++spins > PIPE_SPIN_LIMIT) {
+                if (lane == 0) atomicOr(error_word, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) scg[q] = ld_agent(scrow + q);
+        }
+        const uint64_t pf = ld_agent(reinterpret_cast<const uint64_t *>(prefix16 + (size_t)t * RADIX) + lane);
+        tbase[0] = (uint32_t)scg[0] + (uint32_t)(pf & 0xffffu);
+        tbase[1] = (uint32_t)scg[1] + (uint32_t)((pf >> 16) & 0xffffu);
+        tbase[2] = (uint32_t)scg[2] + (uint32_t)((pf >> 32) & 0xffffu);
+        tbase[3] = (uint32_t)scg[3] + (uint32_t)(pf >> 48);
+    }
+
     // global base of digit run = digit start + tile offset - tile-local start (wave 0, lane l: digits 4l..4l+3)
     auto publish_gbase = [&](const uint32_t (&ex)[4], const uint32_t (&run)[4]) {
-        if (FUSED && !TAIL) {
-            // decoupled look-back (wave 0, lane l owns digits 4l..4l+3): publish this tile's
-            // counts, add up the predecessors' words walking backwards until an inclusive
-            // prefix is met, publish the own inclusive prefix.  Tiles are dispatched in order,
-            // so predecessors are resident or finished; every spin is bounded all the same.
-            uint32_t *mine = status + (size_t)t * RADIX + 4 * lane;
-            if (t == 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) __hip_atomic_store(mine + q, ST_INC | run[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) __hip_atomic_store(mine + q, ST_AGG | run[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint32_t jq[4] = {t - 1, t - 1, t - 1, t - 1};
-                bool done[4] = {false, false, false, false};
-                uint32_t spins = 0;
-                for (;;) {
-                    uint32_t e[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        e[q] = done[q] ? 0u
-                                       : __hip_atomic_load(status + (size_t)jq[q] * RADIX + 4 * lane + q, __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT);
-                    bool waiting = false;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (done[q]) continue;
-                        const uint32_t f = e[q] >> 30;
-                        if (f == 0) { waiting = true; continue; }           // not published yet: retry
-                        tbase[q] += e[q] & ST_VAL;
-                        if (f == 2) done[q] = true; else --jq[q];             // tile 0 always publishes inclusive
-                    }
-                    const bool all_done = done[0] && done[1] && done[2] && done[3];
-                    if (__builtin_amdgcn_ballot_w64(!all_done) == 0) break;
-                    if (__builtin_amdgcn_ballot_w64(waiting) != 0) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > (1u << 22)) {                          // never hang the GPU
-                            if (lane == 0 && error_word) atomicOr(error_word, 1u);
-                            break;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    __hip_atomic_store(mine + q, ST_INC | ((tbase[q] + run[q]) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
         uint32_t g[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) g[q] = dstart[q] + tbase[q] - ex[q];
@@ -610,6 +598,172 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
 #endif
 }
 
+template <bool HAS_VALUES, bool TAIL, int TW, bool BIG>
+__global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep_kernel(
+    const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ vals_in,
+    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint16_t *__restrict__ prefix16,
+    const uint32_t *__restrict__ totals, PassParams p)
+{
+    __shared__ __attribute__((aligned(16))) DownsweepSmem<HAS_VALUES> sm;
+    const uint32_t full_tiles = p.n / (uint32_t)LSB_TILE;
+    if (!TAIL && blockIdx.x >= full_tiles) return;
+    const uint32_t t = TAIL ? full_tiles : tile_of_item(blockIdx.x, full_tiles);
+    downsweep_tile<HAS_VALUES, TAIL, TW, BIG, false>(sm, t, keys_in, keys_out, vals_in, vals_out, spine, prefix16, totals, p,
+                                                     nullptr, 0u, nullptr);
+}
+
+// ---------------------------------------------------------- pipelined pass --
+// One launch = one pass, the north_star's three steps as ROLES of its workgroups:
+//   blocks 0..7        scanner: walk the chunk rows in order and turn the tagged counts the upsweep role publishes
+//                      (`cc`) into exclusive prefixes over the earlier chunks (`sc`), 32 digit columns per block;
+//   upsweep blocks     one chunk each (upsweep_chunk): counts, in-chunk prefixes, and the NEXT pass's digit totals;
+//   downsweep blocks   one tile each (downsweep_tile).
+// Blocks are dispatched in index order, and the index order puts every upsweep block PIPE_LEAD_CHUNKS chunks (1024
+// tiles) ahead of the downsweep blocks of the same keys: 8 upsweep blocks, then the 64 downsweep blocks of 64 tiles
+// whose counts were taken two groups earlier.  So (a) nothing a block waits for depends on a block dispatched after
+// it (the scanner and the upsweep blocks it needs have lower indices), (b) the downsweep reads keys the upsweep
+// brought into the Infinity Cache ~15 us earlier: 4 of the pass's 12 B/key do not reach HBM (tools/micro/mall_reuse.hip:
+// copy + look-ahead read 1.73 ms, copy + unrelated read 2.42 ms, copy alone 1.60 ms), (c) the upsweep's memory waits
+// overlap the downsweep's ranking on the same CUs.  Needs the digit totals BEFORE the launch: the previous pass's
+// upsweep gathers them (NEXT).  Every wait is bounded and reports through `error_word`.
+// Scanner role.  The upsweep role publishes 8.75 chunk rows per microsecond at 2^30 keys and a dependent read takes
+// 4-8 us under the pass's own load, so far more than 100 rows must be in flight: the 8 scanner blocks (one per XCD
+// round-robin slot) are 64 INDEPENDENT waves, each owning 4 digit columns; inside a wave the 16 lanes of a DPP row
+// share one digit and take 4 consecutive rows each, so a batch is 64 rows, its prefix is a DPP row scan (no LDS, no
+// barrier), and PIPE_SCAN_AHEAD batches are requested before the oldest is consumed (256 rows in flight per wave).
+// A batch is written once all its rows carry the tag: it must stay shorter than the upsweep's lead (deadlock
+// otherwise: downsweep blocks waiting for rows whose upsweep blocks are dispatched behind them).
+constexpr int PIPE_SCAN_K = 4;                           // rows per lane and batch
+constexpr int PIPE_SCAN_AHEAD = 3;                       // batches requested ahead of the one being consumed
+constexpr uint32_t PIPE_ROW_PAD = 16 * PIPE_SCAN_K;      // batch length; cc / sc have this many rows beyond the last chunk
+static_assert(PIPE_ROW_PAD < PIPE_LEAD_CHUNKS, "a scanner batch must be shorter than the upsweep's lead");
+
+// inclusive scan inside each DPP row of 16 lanes
+__device__ __forceinline__ uint32_t row16_inclusive_scan(uint32_t x)
+{
+    uint32_t v = x;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false);  // row_shr:3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);  // row_shr:4, banks 1-3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);  // row_shr:8, banks 2-3
+    return v;
+}
+
+// `rows` is a multiple of the batch: the upsweep role publishes zero counts for the rows past the last chunk.
+__device__ __forceinline__ void pipe_scan_rows(uint32_t slice, const uint32_t *__restrict__ cc, uint64_t *__restrict__ sc,
+                                               uint32_t rows, uint32_t tag, uint32_t *__restrict__ error_word)
+{
+    constexpr int K = PIPE_SCAN_K, A = PIPE_SCAN_AHEAD;
+    const int lane = lane_id();
+    const uint32_t d = slice * 32u + (uint32_t)wave_id() * 4u + ((uint32_t)lane >> 4);   // my digit column
+    const uint32_t g = (uint32_t)lane & 15u;                                              // my row lane
+    const uint32_t nb = rows / PIPE_ROW_PAD;
+    // 32-bit byte offsets from the scalar bases (<= 64 MiB and 128 MiB at 2^32 keys), rows at constant distances
+    auto off_of = [&](uint32_t b) { return ((b * PIPE_ROW_PAD + g * K) * (uint32_t)RADIX + d) * 4u; };
+    auto request = [&](uint32_t (&v)[K], uint32_t b) {
+        uint32_t off = off_of(b);
+        asm volatile("" : "+v"(off));
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            v[k] = ld_agent(reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(cc) + (off + (uint32_t)k * RADIX * 4u)));
+    };
+    uint32_t run = 0;
+    auto consume = [&](uint32_t (&v)[K], uint32_t b) {
+        uint32_t spins = 0;
+        for (;;) {
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < K; ++k) bad |= (v[k] >> 28) != tag;
+            if (__builtin_amdgcn_ballot_w64(bad) == 0) break;
+            if (++spins > PIPE_SPIN_LIMIT) {
+                if (lane == 0) atomicOr(error_word, 2u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+            request(v, b);
+        }
+        uint32_t tot = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { v[k] &= 0x0fffffffu; tot += v[k]; }
+        const uint32_t inc = row16_inclusive_scan(tot);
+        uint32_t acc = run + inc - tot;
+        run += (uint32_t)__shfl((int)inc, lane | 15, WAVE);   // the row's total
+        const uint32_t off8 = off_of(b) * 2u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            st_agent(reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(sc) + (off8 + (uint32_t)k * RADIX * 8u)),
+                     ((uint64_t)tag << 32) | (uint64_t)acc);
+            acc += v[k];
+        }
+    };
+    static_assert(A == 3, "the ring below is written out for three batches ahead");
+    uint32_t v0[K], v1[K], v2[K], v3[K];
+    if (nb > 0) request(v0, 0);
+    if (nb > 1) request(v1, 1);
+    if (nb > 2) request(v2, 2);
+#pragma unroll 1
+    for (uint32_t b = 0; b < nb; b += 4) {
+        if (b + 3 < nb) request(v3, b + 3);
+        consume(v0, b);
+        if (b + 1 >= nb) break;
+        if (b + 4 < nb) request(v0, b + 4);
+        consume(v1, b + 1);
+        if (b + 2 >= nb) break;
+        if (b + 5 < nb) request(v1, b + 5);
+        consume(v2, b + 2);
+        if (b + 3 >= nb) break;
+        if (b + 6 < nb) request(v2, b + 6);
+        consume(v3, b + 3);
+    }
+}
+
+template <bool HAS_VALUES>
+union PipeSmem {
+    DownsweepSmem<HAS_VALUES> ds;
+    UpsweepSmem<true, true> us;
+    UpsweepSmem<false, true> us1;
+};
+
+template <bool HAS_VALUES, int TW, bool BIG>
+__global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_pipe_pass_kernel(
+    const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ vals_in,
+    uint32_t *__restrict__ vals_out, uint32_t *__restrict__ cc, uint64_t *__restrict__ sc, uint16_t *__restrict__ prefix16,
+    const uint32_t *__restrict__ totals, uint32_t *__restrict__ next_totals, uint32_t *__restrict__ error_word, PassParams p,
+    PipeParams q)
+{
+    __shared__ __attribute__((aligned(16))) PipeSmem<HAS_VALUES> sm;
+    uint32_t x = blockIdx.x;
+    if (x < MI355X_XCDS) {       // the scanner: a whole round of the XCD round-robin, so that downsweep item i sits on XCD i % 8
+        pipe_scan_rows(x, cc, sc, q.scan_rows, q.tag, error_word);
+        return;
+    }
+    x -= MI355X_XCDS;
+    uint32_t chunk;
+    if (x < q.lead_chunks) {
+        chunk = x;
+    } else {
+        x -= q.lead_chunks;
+        const uint32_t g = x / PIPE_GROUP_BLOCKS, r = x % PIPE_GROUP_BLOCKS, sub = r / PIPE_SUB_BLOCKS, s = r % PIPE_SUB_BLOCKS;
+        if (s >= 8u) {
+            const uint32_t full_tiles = p.n / (uint32_t)LSB_TILE;
+            const uint32_t item = g * (uint32_t)LSB_GROUP + sub * 64u + (s - 8u);
+            if (item >= full_tiles) return;
+            downsweep_tile<HAS_VALUES, false, TW, BIG, true>(sm.ds, tile_of_item(item, full_tiles), keys_in, keys_out, vals_in,
+                                                             vals_out, nullptr, prefix16, totals, p, sc, q.tag, error_word);
+            return;
+        }
+        chunk = q.lead_chunks + g * (uint32_t)(LSB_GROUP / LSB_CHUNK) + sub * 8u + s;
+    }
+    if (chunk >= p.grid) {   // rows past the last chunk: zero counts, so the scanner's batches are whole
+        if (chunk < q.scan_rows && threadIdx.x < RADIX / 2)
+            st_agent(reinterpret_cast<uint64_t *>(cc + (size_t)chunk * RADIX) + threadIdx.x, ((uint64_t)(q.tag << 28) << 32) | (q.tag << 28));
+        return;
+    }
+    if (q.next_bits) upsweep_chunk<true, true>(sm.us, keys_in, chunk, nullptr, prefix16, cc, next_totals, p, q);
+    else upsweep_chunk<false, true>(sm.us1, keys_in, chunk, nullptr, prefix16, cc, next_totals, p, q);
+}
+
 // ------------------------------------------------------------------- host --
 
 static inline uint32_t lsb_num_tiles(uint64_t n) { return (uint32_t)((n + LSB_TILE - 1) / LSB_TILE); }
@@ -654,17 +808,31 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline size_t spine_bytes(uint64_t n) { return align256((size_t)RADIX * lsb_grid(n) * sizeof(uint32_t)); }
 static inline size_t totals_bytes() { return align256(RADIX * sizeof(uint32_t)); }
 static inline size_t prefix16_bytes(uint64_t n) { return align256((size_t)lsb_num_tiles(n) * RADIX * sizeof(uint16_t)); }
-// single-sweep mode (n <= 2^30: 30-bit prefixes): digit totals of 4 passes + error word, and the look-back words
-static inline bool fused_enabled()
-{
-    static const char *e = getenv("GS_LSB_MODE");   // read once per process: sizes and strategy stay consistent
-    return e && strcmp(e, "fused") == 0;
-}
-static inline bool fused_possible(uint64_t n) { return fused_enabled() && n <= (1ull << 30) && n >= (uint64_t)LSB_TILE; }
-static inline size_t totals4_bytes() { return align256(4 * RADIX * sizeof(uint32_t)) + 256; }
-static inline size_t status_bytes(uint64_t n) { return fused_possible(n) ? align256((n / LSB_TILE) * RADIX * sizeof(uint32_t)) : 0; }
+// pipelined passes: tagged chunk counts, scanned granules, digit totals per pass, error word -- one block, zeroed per sort
+static inline size_t cc_bytes(uint64_t n) { return align256((size_t)RADIX * (lsb_grid(n) + PIPE_ROW_PAD) * sizeof(uint32_t)); }
+static inline size_t sc_bytes(uint64_t n) { return align256((size_t)RADIX * (lsb_grid(n) + PIPE_ROW_PAD) * sizeof(uint64_t)); }
+static inline size_t ptotals_bytes() { return align256(5 * RADIX * sizeof(uint32_t)) + 256; }
+static inline size_t pipe_bytes(uint64_t n) { return cc_bytes(n) + sc_bytes(n) + ptotals_bytes(); }
 
-size_t lsb_temp_bytes(uint64_t n) { return spine_bytes(n) + totals_bytes() + prefix16_bytes(n) + totals4_bytes() + status_bytes(n); }
+// LSB pass strategy.  "three" = upsweep -> scan -> downsweep as three launches per pass.  "pipe" (default for arrays
+// of more than LSB_SMALL_TILES tiles) = the first pass as three launches, every later pass as ONE launch whose
+// workgroups take the three roles (lsb_pipe_pass_kernel).  Same steps, same results; GS_LSB_MODE=three|pipe selects.
+static inline bool pipe_enabled()
+{
+    static const char *e = getenv("GS_LSB_MODE");   // read once per process
+    return !(e && strcmp(e, "three") == 0);
+}
+
+// smallest array (in tiles) that takes pipelined passes; GS_LSB_PIPE_MIN_TILES lowers it so tests reach the kernel with small inputs
+static inline uint32_t pipe_min_tiles()
+{
+    static const uint32_t v = [] { const char *e = getenv("GS_LSB_PIPE_MIN_TILES"); return e ? (uint32_t)strtoul(e, nullptr, 10) : LSB_SMALL_TILES + 1u; }();
+    return v;
+}
+
+static inline bool pipe_size_ok(uint64_t n) { return pipe_enabled() && lsb_num_tiles(n) >= pipe_min_tiles() && n > small_sort_capacity(false); }
+
+size_t lsb_temp_bytes(uint64_t n) { return spine_bytes(n) + totals_bytes() + prefix16_bytes(n) + pipe_bytes(n); }
 LsbWorkspace lsb_carve(void *temp, uint64_t n)
 {
     char *c = (char *)temp;
@@ -672,16 +840,28 @@ LsbWorkspace lsb_carve(void *temp, uint64_t n)
     ws.spine = (uint32_t *)c;
     ws.totals = (uint32_t *)(c + spine_bytes(n));
     ws.prefix16 = (uint16_t *)(c + spine_bytes(n) + totals_bytes());
-    ws.totals4 = (uint32_t *)(c + spine_bytes(n) + totals_bytes() + prefix16_bytes(n));
-    ws.error_word = ws.totals4 + 4 * RADIX;
-    ws.status = fused_possible(n) ? (uint32_t *)((char *)ws.totals4 + totals4_bytes()) : nullptr;
+    char *pb = c + spine_bytes(n) + totals_bytes() + prefix16_bytes(n);
+    ws.cc = (uint32_t *)pb;
+    ws.sc = (uint64_t *)(pb + cc_bytes(n));
+    ws.ptotals = (uint32_t *)(pb + cc_bytes(n) + sc_bytes(n));
+    ws.error_word = ws.ptotals + 5 * RADIX;
     return ws;
 }
 
 int lsb_upsweep(const uint32_t *keys, uint32_t *spine, uint16_t *prefix16, const PassParams &p, hipStream_t s)
 {
     KernelTimer kt(GS_K_LSB_UPSWEEP, s);
-    hipLaunchKernelGGL(lsb_upsweep_kernel, dim3(p.grid), dim3(LSB_THREADS), 0, s, keys, spine, prefix16, p);
+    hipLaunchKernelGGL(lsb_upsweep_kernel<false>, dim3(p.grid), dim3(LSB_THREADS), 0, s, keys, spine, prefix16,
+                       (uint32_t *)nullptr, p, PipeParams{});
+    return (int)hipGetLastError();
+}
+
+// the same, also gathering the digit totals of the pass that follows (into next_totals, zeroed by the caller)
+static int lsb_upsweep_next(const uint32_t *keys, uint32_t *spine, uint16_t *prefix16, uint32_t *next_totals, const PassParams &p,
+                            const PipeParams &q, hipStream_t s)
+{
+    KernelTimer kt(GS_K_LSB_UPSWEEP, s);
+    hipLaunchKernelGGL(lsb_upsweep_kernel<true>, dim3(p.grid), dim3(LSB_THREADS), 0, s, keys, spine, prefix16, next_totals, p, q);
     return (int)hipGetLastError();
 }
 
@@ -699,10 +879,10 @@ static void launch_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t
     const dim3 block(LSB_THREADS);
     if (vin)
         hipLaunchKernelGGL((lsb_downsweep_kernel<true, false, TW, BIG>), dim3(p.ds_grid), block, 0, s, kin, kout, vin, vout,
-                           spine, prefix16, totals, p, (uint32_t *)nullptr, (uint32_t *)nullptr);
+                           spine, prefix16, totals, p);
     else
         hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, TW, BIG>), dim3(p.ds_grid), block, 0, s, kin, kout, vin, vout,
-                           spine, prefix16, totals, p, (uint32_t *)nullptr, (uint32_t *)nullptr);
+                           spine, prefix16, totals, p);
 }
 
 static void launch_downsweep_tail(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
@@ -711,12 +891,10 @@ static void launch_downsweep_tail(const uint32_t *kin, uint32_t *kout, const uin
     const dim3 block(LSB_THREADS);   // one block, the general variant
     if (vin)
         hipLaunchKernelGGL((lsb_downsweep_kernel<true, true, 2, true>), dim3(1), block, 0, s, kin, kout, vin, vout,
-                           (const uint32_t *)nullptr, (const uint16_t *)nullptr, totals, p, (uint32_t *)nullptr,
-                           (uint32_t *)nullptr);
+                           (const uint32_t *)nullptr, (const uint16_t *)nullptr, totals, p);
     else
         hipLaunchKernelGGL((lsb_downsweep_kernel<false, true, 2, true>), dim3(1), block, 0, s, kin, kout, vin, vout,
-                           (const uint32_t *)nullptr, (const uint16_t *)nullptr, totals, p, (uint32_t *)nullptr,
-                           (uint32_t *)nullptr);
+                           (const uint32_t *)nullptr, (const uint16_t *)nullptr, totals, p);
 }
 
 int lsb_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, const uint32_t *spine,
@@ -735,12 +913,36 @@ int lsb_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint
     return (int)hipGetLastError();
 }
 
-// LSB pass strategy.  "three" = upsweep -> scan -> downsweep per pass (the north_star's
-// formulation; 48 B/key for 4 passes).  "fused" = single-sweep: ONE histogram kernel gives the
-// digit totals of every pass, and each pass is a single scatter whose tiles get their offsets
-// by decoupled look-back (36 B/key); available for n <= 2^30.  Selected by GS_LSB_MODE
-// ("three" | "fused"); results are identical.
-static bool lsb_use_fused(uint64_t n) { return fused_possible(n); }
+template <int TW, bool BIG>
+static void launch_pipe_pass(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, const LsbWorkspace &ws,
+                             const uint32_t *totals, uint32_t *next_totals, const PassParams &p, const PipeParams &q, uint32_t blocks,
+                             hipStream_t s)
+{
+    const dim3 block(LSB_THREADS);
+    if (vin)
+        hipLaunchKernelGGL((lsb_pipe_pass_kernel<true, TW, BIG>), dim3(blocks), block, 0, s, kin, kout, vin, vout, ws.cc, ws.sc,
+                           ws.prefix16, totals, next_totals, ws.error_word, p, q);
+    else
+        hipLaunchKernelGGL((lsb_pipe_pass_kernel<false, TW, BIG>), dim3(blocks), block, 0, s, kin, kout, vin, vout, ws.cc, ws.sc,
+                           ws.prefix16, totals, next_totals, ws.error_word, p, q);
+}
+
+// one pipelined pass: all full tiles in one launch (+ the partial last tile, which needs the digit totals only)
+static int lsb_pipe_pass(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, const LsbWorkspace &ws,
+                         const uint32_t *totals, uint32_t *next_totals, const PassParams &p, const PipeParams &q, hipStream_t s)
+{
+    KernelTimer kt(GS_K_LSB_PASS, s);
+    const uint32_t full = p.n / (uint32_t)LSB_TILE, groups = (full + LSB_GROUP - 1u) / LSB_GROUP;
+    const uint32_t blocks = MI355X_XCDS + q.lead_chunks + groups * PIPE_GROUP_BLOCKS;
+    const int tw = (p.f32_in || p.f32_out) ? 2 : ((p.xor_in | p.xor_out) ? 1 : 0);
+    const bool big = p.n > (1u << 30);
+#define GS_PP(TW_, BIG_) launch_pipe_pass<TW_, BIG_>(kin, kout, vin, vout, ws, totals, next_totals, p, q, blocks, s)
+    if (big) { if (tw == 2) GS_PP(2, true); else if (tw == 1) GS_PP(1, true); else GS_PP(0, true); }
+    else { if (tw == 2) GS_PP(2, false); else if (tw == 1) GS_PP(1, false); else GS_PP(0, false); }
+#undef GS_PP
+    if (p.n % (uint32_t)LSB_TILE) launch_downsweep_tail(kin, kout, vin, vout, totals, p, s);
+    return (int)hipGetLastError();
+}
 
 template <typename Route>
 static int lsb_run_passes(const LsbWorkspace &ws, uint64_t num_items, int begin_bit, int end_bit, int descending,
@@ -748,7 +950,14 @@ static int lsb_run_passes(const LsbWorkspace &ws, uint64_t num_items, int begin_
 {
     const int num_bits = end_bit - begin_bit;
     const int num_passes = (num_bits + RADIX_BITS - 1) / RADIX_BITS;
-    const bool fused = lsb_use_fused(num_items) && ws.status;
+    const bool pipe = num_passes > 1 && pipe_size_ok(num_items);
+    if (pipe) {   // tags, totals and the error word start from zero
+        const hipError_t me = zero_async(ws.cc, pipe_bytes(num_items), s);
+        if (me != hipSuccess) return (int)me;
+    } else if (pipe_size_ok(num_items)) {   // a size gs_lsb_pipe_status reads the word for: keep it meaningful
+        const hipError_t me = zero_async(ws.error_word, 8, s);
+        if (me != hipSuccess) return (int)me;
+    }
     for (int pass = 0; pass < num_passes; ++pass) {
         const int shift = begin_bit + pass * RADIX_BITS;
         const int bits = (end_bit - shift < RADIX_BITS) ? end_bit - shift : RADIX_BITS;
@@ -758,55 +967,35 @@ static int lsb_run_passes(const LsbWorkspace &ws, uint64_t num_items, int begin_
         uint32_t *kout, *vout;
         route(pass, num_passes, kin, kout, vin, vout);
         if (!pairs) { vin = nullptr; vout = nullptr; }
-        int e;
-        if (!fused) {
-            if (p.num_tiles <= LSB_SMALL_TILES) {   // latency-bound sizes: workgroup per tile, chunk prefixes in the scan
-                { KernelTimer kt(GS_K_LSB_UPSWEEP, s);
-                  hipLaunchKernelGGL(lsb_upsweep_small_kernel, dim3(p.num_tiles), dim3(LSB_THREADS), 0, s, kin, ws.prefix16, p); }
-                { KernelTimer kt(GS_K_LSB_SCAN, s);
-                  hipLaunchKernelGGL(lsb_scan_small_kernel, dim3(RADIX), dim3(RADIX), 0, s, ws.spine, ws.totals, ws.prefix16, p.grid,
-                                     p.num_tiles); }
-                if ((e = (int)hipGetLastError())) return e;
-            } else {
-            if ((e = lsb_upsweep(kin, ws.spine, ws.prefix16, p, s))) return e;
-            if ((e = lsb_scan(ws.spine, ws.totals, p.grid, s))) return e;
+        PipeParams q{};
+        if (pipe) {
+            q.tag = (uint32_t)pass + 1u;
+            q.lead_chunks = PIPE_LEAD_CHUNKS;
+            q.scan_rows = (p.grid + PIPE_ROW_PAD - 1u) / PIPE_ROW_PAD * PIPE_ROW_PAD;   // whole scanner batches (<= grid + pad - 1)
+            if (pass + 1 < num_passes) {
+                q.next_shift = (uint32_t)(shift + RADIX_BITS);
+                q.next_bits = (uint32_t)((end_bit - (int)q.next_shift < RADIX_BITS) ? end_bit - (int)q.next_shift : RADIX_BITS);
             }
-            if ((e = lsb_downsweep(kin, kout, vin, vout, ws.spine, ws.prefix16, ws.totals, p, s))) return e;
+        }
+        int e;
+        if (pipe && pass > 0) {
+            uint32_t *next_totals = ws.ptotals + (size_t)(pass + 1) * RADIX;
+            if ((e = lsb_pipe_pass(kin, kout, vin, vout, ws, ws.ptotals + (size_t)pass * RADIX, next_totals, p, q, s))) return e;
             continue;
         }
-        if (pass == 0) {   // digit totals of all passes from one read of the input
-            Hist4Params hp{};
-            hp.n = p.n; hp.num_passes = num_passes; hp.f32_in = p.f32_in; hp.xor_in = p.xor_in;
-            for (int q = 0; q < num_passes; ++q) {
-                hp.shift[q] = (uint32_t)(begin_bit + q * RADIX_BITS);
-                hp.bits[q] = (uint32_t)((end_bit - (int)hp.shift[q] < RADIX_BITS) ? end_bit - (int)hp.shift[q] : RADIX_BITS);
-            }
-            hipError_t me = zero_async(ws.totals4, totals4_bytes(), s);
-            if (me != hipSuccess) return (int)me;
-            KernelTimer kt(GS_K_LSB_UPSWEEP, s);
-            const uint32_t g = p.num_tiles < 2048u ? p.num_tiles : 2048u;
-            if (((uintptr_t)kin & 15u) == 0)
-                hipLaunchKernelGGL(lsb_hist4_kernel<true>, dim3(g), dim3(LSB_THREADS), 0, s, kin, ws.totals4, hp);
-            else
-                hipLaunchKernelGGL(lsb_hist4_kernel<false>, dim3(g), dim3(LSB_THREADS), 0, s, kin, ws.totals4, hp);
+        if (p.num_tiles <= LSB_SMALL_TILES && !pipe) {   // latency-bound sizes: workgroup per tile, chunk prefixes in the scan
+            { KernelTimer kt(GS_K_LSB_UPSWEEP, s);
+              hipLaunchKernelGGL(lsb_upsweep_small_kernel, dim3(p.num_tiles), dim3(LSB_THREADS), 0, s, kin, ws.prefix16, p); }
+            { KernelTimer kt(GS_K_LSB_SCAN, s);
+              hipLaunchKernelGGL(lsb_scan_small_kernel, dim3(RADIX), dim3(RADIX), 0, s, ws.spine, ws.totals, ws.prefix16, p.grid,
+                                 p.num_tiles); }
+            if ((e = (int)hipGetLastError())) return e;
+        } else {
+            if (pipe) { if ((e = lsb_upsweep_next(kin, ws.spine, ws.prefix16, ws.ptotals + RADIX, p, q, s))) return e; }
+            else if ((e = lsb_upsweep(kin, ws.spine, ws.prefix16, p, s))) return e;
+            if ((e = lsb_scan(ws.spine, ws.totals, p.grid, s))) return e;
         }
-        hipError_t me = zero_async(ws.status, status_bytes(num_items), s);
-        if (me != hipSuccess) return (int)me;
-        const uint32_t *tot = ws.totals4 + pass * RADIX;
-        {
-            KernelTimer kt(GS_K_LSB_DOWNSWEEP, s);
-            const dim3 block(LSB_THREADS);
-            if (vin)
-                hipLaunchKernelGGL((lsb_downsweep_kernel<true, false, 2, false, true>), dim3(p.ds_grid), block, 0, s, kin, kout,
-                                   vin, vout, (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, ws.status,
-                                   ws.error_word);
-            else
-                hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, 2, false, true>), dim3(p.ds_grid), block, 0, s, kin, kout,
-                                   vin, vout, (const uint32_t *)nullptr, (const uint16_t *)nullptr, tot, p, ws.status,
-                                   ws.error_word);
-            if (p.n % (uint32_t)LSB_TILE) launch_downsweep_tail(kin, kout, vin, vout, tot, p, s);
-        }
-        if ((e = (int)hipGetLastError())) return e;
+        if ((e = lsb_downsweep(kin, kout, vin, vout, ws.spine, ws.prefix16, ws.totals, p, s))) return e;
     }
     return hipSuccess;
 }
@@ -891,6 +1080,18 @@ int gs_lsb_workspace_layout(void *d_temp, uint64_t num_items, uint32_t **d_spine
     return hipSuccess;
 }
 
+int gs_lsb_pipe_status(void *d_temp, uint64_t num_items, uint32_t *h_status, void *stream)
+{
+    GS_CLEAR_STALE_ERROR();
+    if (!d_temp || !h_status || num_items >= (1ull << 32)) return hipErrorInvalidValue;
+    *h_status = 0;
+    if (!pipe_size_ok(num_items)) return hipSuccess;   // such arrays never take pipelined passes
+    const LsbWorkspace ws = lsb_carve(d_temp, num_items);
+    hipError_t e = hipMemcpyAsync(h_status, ws.error_word, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    return (int)e;
+}
+
 int gs_lsb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], uint32_t *d_vals[2], int *selector,
                     uint64_t num_items, int begin_bit, int end_bit, int descending, int key_type, void *stream)
 {
@@ -904,7 +1105,7 @@ int gs_lsb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], uint32
     if (!d_keys[0] || !d_keys[1] || (d_vals && (!d_vals[0] || !d_vals[1]))) return hipErrorInvalidValue;
 
     int sel = *selector;
-    if (num_items <= small_sort_capacity(d_vals != nullptr) && !fused_enabled()) {
+    if (num_items <= small_sort_capacity(d_vals != nullptr)) {
         // fits one workgroup: one launch (CUB's single-tile path); the result lands where the passes would leave it
         const int passes = (end_bit - begin_bit + RADIX_BITS - 1) / RADIX_BITS, fin = sel ^ (passes & 1);
         PassParams tw{};
@@ -958,7 +1159,7 @@ int gs_lsb_sort_copy_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys
             e = hipMemcpyAsync(d_vals_out, d_vals_in, num_items * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
         return (int)e;
     }
-    if (num_items <= small_sort_capacity(pairs) && !fused_enabled()) {   // one workgroup, straight from IN to OUT
+    if (num_items <= small_sort_capacity(pairs)) {   // one workgroup, straight from IN to OUT
         PassParams tw{};
         lsb_twiddle_masks(key_type, descending, true, true, tw);
         return small_stable_sort(d_temp, temp_bytes, d_keys_in, d_keys_out, d_vals_in, d_vals_out, (uint32_t)num_items, begin_bit,

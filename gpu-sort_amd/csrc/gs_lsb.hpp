@@ -45,13 +45,27 @@ __device__ __forceinline__ uint32_t tile_of_item(uint32_t i, uint32_t full_tiles
     return base + (r % MI355X_XCDS) * (LSB_RESIDENT / MI355X_XCDS) + r / MI355X_XCDS;
 }
 
+// Pipelined pass (gs_lsb.hip, lsb_pipe_pass_kernel): the three steps of a pass run inside ONE launch, the upsweep a
+// bounded distance ahead of the downsweep, so that the downsweep's re-read of the keys is served by the Infinity Cache.
+struct PipeParams {
+    uint32_t tag;                  // pass index + 1: marks the words this pass published (never 0)
+    uint32_t lead_chunks;          // upsweep blocks dispatched before the first downsweep block (multiple of 8)
+    uint32_t scan_rows;            // rows the scanner walks: the chunks, rounded up to whole scanner batches
+    uint32_t next_shift, next_bits;   // digit of the NEXT pass, whose totals the upsweep gathers on the way (0 bits: none)
+};
+constexpr uint32_t PIPE_LEAD_CHUNKS = 128;   // 1024 tiles = 32 MiB of keys ahead (re-read window of the Infinity Cache: < 2048 tiles)
+constexpr uint32_t PIPE_SUB_BLOCKS = 72;     // 8 upsweep blocks (chunks) followed by the 64 downsweep blocks of 64 tiles
+constexpr uint32_t PIPE_GROUP_BLOCKS = PIPE_SUB_BLOCKS * (LSB_GROUP / 64);
+
 struct LsbWorkspace {
     uint32_t *spine;
     uint32_t *totals;
     uint16_t *prefix16;
-    uint32_t *totals4;      // single-sweep mode: digit totals of up to 4 passes
-    uint32_t *error_word;   // single-sweep mode: set if a bounded spin ever gave up
-    uint32_t *status;       // single-sweep mode: look-back words [full tiles][256]; nullptr if n > 2^30
+    // pipelined passes: all zeroed once per sort
+    uint32_t *cc;           // [chunks][256] chunk counts, tag in bits 31:28
+    uint64_t *sc;           // [chunks][256] {tag, exclusive prefix over the earlier chunks}
+    uint32_t *ptotals;      // [5][256] digit totals of pass q in row q (row 0 unused: the scan kernel writes `totals`)
+    uint32_t *error_word;   // set if a bounded spin ever gave up
 };
 
 size_t lsb_temp_bytes(uint64_t n);

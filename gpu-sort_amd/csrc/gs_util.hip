@@ -190,7 +190,7 @@ int gs_profile_read(gs_profile *p, double total_ms[GS_K_COUNT], uint64_t launche
 const char *gs_kernel_name(int id)
 {
     static const char *names[GS_K_COUNT] = {"lsb_upsweep", "lsb_scan", "lsb_downsweep", "msb_histogram", "msb_classify",
-                                            "msb_partition", "msb_local_sort", "shard", "other"};
+                                            "msb_partition", "msb_local_sort", "shard", "other", "lsb_pass"};
     return (id >= 0 && id < GS_K_COUNT) ? names[id] : "?";
 }
 

@@ -109,6 +109,12 @@ void gs_lsb_geometry(uint64_t num_items, int has_values, uint32_t *grid, uint32_
                      uint32_t *tiles_per_chunk);
 int  gs_lsb_workspace_layout(void *d_temp, uint64_t num_items, uint32_t **d_spine,
                              uint32_t **d_totals, uint16_t **d_prefix16);
+/* Pipelined passes (one launch per pass, the three steps as roles of its workgroups): every wait
+ * inside such a launch is bounded; a wait that gave up sets a bit of the workspace's status word
+ * (1 = a downsweep tile, 2 = the scanner) and the sort's output is then invalid.  Copies the word of
+ * the last sort that used d_temp to *h_status after synchronising `stream` (0 = clean, also for
+ * sorts that ran no pipelined pass).  Diagnostic: tests and benches read it.                      */
+int  gs_lsb_pipe_status(void *d_temp, uint64_t num_items, uint32_t *h_status, void *stream);
 int  gs_lsb_upsweep_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_keys_in,
                         uint64_t num_items, int shift, int bits, int descending,
                         int key_type_in, void *stream);
@@ -234,7 +240,9 @@ int gs_check_pairs_enumerated_u32(const uint32_t *d_keys_in, const uint32_t *d_k
 enum gs_kernel_id {
     GS_K_LSB_UPSWEEP = 0, GS_K_LSB_SCAN = 1, GS_K_LSB_DOWNSWEEP = 2,
     GS_K_MSB_HISTOGRAM = 3, GS_K_MSB_CLASSIFY = 4, GS_K_MSB_PARTITION = 5, GS_K_MSB_LOCAL_SORT = 6,
-    GS_K_SHARD = 7, GS_K_OTHER = 8, GS_K_COUNT = 9
+    GS_K_SHARD = 7, GS_K_OTHER = 8,
+    GS_K_LSB_PASS = 9,   /* a whole pass in one launch (upsweep / scan / downsweep as roles of one kernel) */
+    GS_K_COUNT = 10
 };
 typedef struct gs_profile gs_profile;
 gs_profile *gs_profile_create(void);
