@@ -55,7 +55,27 @@ def parse_args():
                     help="run the bucket-sharded pipeline even on one rank (exercises the N>1 code path)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 rehearsal where every rank uses cuda:0 and the exchange goes over gloo (not a measurement)")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="launch plumbing only (CPU, gloo): spawn the ranks, rendezvous, one all_reduce, rank 0 prints a "
+                         "JSON line with n_gpus -- what tests/test_bench_launch.py runs where there is no GPU")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves as CHILD processes
+    (python -m torch.distributed.run, one rank per GPU), before anything in this process has touched the GPU, pass
+    their output through and exit with their code.  Rank 0 prints the single JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:          # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def load_pmc_traffic():
@@ -81,6 +101,11 @@ def cpu_baseline(n_log2, pairs):
     out = {"value": n / dt / 1e9, "unit": "Gkeys/s", "cores": 1, "kind": "port",
            "sample": f"first 2^{n_log2} keys of the step-0 input (uniform splitmix64, seed 0), {what}, 1 thread, {dt:.2f} s",
            "host_threads_available": O.hardware_threads()}
+    # BASELINE.json configs[0]: the reference's CPU path at 2^20 keys, median of 5
+    k20 = O.gen_uniform(1 << 20, seed=0)
+    t20 = sorted(O.time_std_sort(k20)[0] for _ in range(5))
+    out["config1_2p20"] = {"value": (1 << 20) / t20[2] / 1e9, "unit": "Gkeys/s", "cores": 1, "ms_median_of_5": round(t20[2] * 1e3, 3),
+                           "ms_min": round(t20[0] * 1e3, 3), "sample": "2^20 uniform u32 keys, std::sort, 1 thread"}
     if not pairs:
         dt_mt, used, _ = O.time_std_sort_mt(keys, 0)
         out["all_cores"] = {"value": n / dt_mt / 1e9, "unit": "Gkeys/s", "cores": used,
@@ -90,15 +115,29 @@ def cpu_baseline(n_log2, pairs):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+    if world != max(args.gpus, 1):
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    if args.dry_run_launch:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "launch plumbing only", "dry_run": True, "n_gpus": world,
+                              "rank_sum": float(t.item()), "steps": args.steps, "warmup": args.warmup}), flush=True)
+        dist.destroy_process_group()
+        return
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -205,13 +244,20 @@ def main():
         runner.groups = min(probe, key=probe.get)
         barrier()
     prof = gs.KernelProfile()
+    # BASELINE.md sections 3-4 / SURVEY.md 8d: besides the wall clock over the K steps (the contract's `value`), every
+    # step is bracketed by an event pair on the stream the sort is enqueued on -> median and min of the per-step device time
+    step_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
     with prof:
         for i in range(warmup, total):
+            ea, eb = step_events[i - warmup]
+            ea.record()
             one_step(i)
+            eb.record()
     barrier()
     elapsed = time.perf_counter() - t0
     kernels = prof.read()
+    step_ms = sorted(a.elapsed_time(b) for a, b in step_events)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
@@ -274,7 +320,10 @@ def main():
         line = {
             "metric": "Gkeys/s sorting 2^30 uint32 keys; achieved HBM GB/s vs roofline",
             "value": round(value, 3), "unit": "Gkeys/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_per_step, 4),
+            "step_ms_device": {"median": round(step_ms[len(step_ms) // 2], 4), "min": round(step_ms[0], 4),
+                               "max": round(step_ms[-1], 4), "how": "hipEvent pair around every timed step on the sort's stream (rank 0)"},
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo)" if args.rehearse_on_one_gpu else "") + (" (one-rank RCCL group: the exchange is a device-local copy)" if args.one_rank_rccl else ""),
             "config": {"workload": (f"{algo}_radix_sort_2^{args.log2n}_u32_{args.dist}_"
                                     f"{'pairs' if args.pairs else 'keys_only'}" + ("_per_gpu_sharded" if sharded_path else "")),

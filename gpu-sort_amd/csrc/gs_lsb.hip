@@ -812,7 +812,7 @@ static inline size_t prefix16_bytes(uint64_t n) { return align256((size_t)lsb_nu
 static inline size_t cc_bytes(uint64_t n) { return align256((size_t)RADIX * (lsb_grid(n) + PIPE_ROW_PAD) * sizeof(uint32_t)); }
 static inline size_t sc_bytes(uint64_t n) { return align256((size_t)RADIX * (lsb_grid(n) + PIPE_ROW_PAD) * sizeof(uint64_t)); }
 static inline size_t ptotals_bytes() { return align256(5 * RADIX * sizeof(uint32_t)) + 256; }
-static inline size_t pipe_bytes(uint64_t n) { return cc_bytes(n) + sc_bytes(n) + ptotals_bytes(); }
+static inline size_t pipe_bytes_full(uint64_t n) { return cc_bytes(n) + sc_bytes(n) + ptotals_bytes(); }
 
 // LSB pass strategy.  "three" (default) = upsweep -> scan -> downsweep as three launches per pass.  "pipe" = the
 // first pass as three launches, every later pass as ONE launch whose workgroups take the three roles
@@ -835,6 +835,8 @@ static inline uint32_t pipe_min_tiles()
 
 static inline bool pipe_size_ok(uint64_t n) { return pipe_enabled() && lsb_num_tiles(n) >= pipe_min_tiles() && n > small_sort_capacity(false); }
 
+// the pipelined passes' block exists only in processes that asked for them (the error word always does)
+static inline size_t pipe_bytes(uint64_t n) { return pipe_enabled() ? pipe_bytes_full(n) : ptotals_bytes(); }
 size_t lsb_temp_bytes(uint64_t n) { return spine_bytes(n) + totals_bytes() + prefix16_bytes(n) + pipe_bytes(n); }
 LsbWorkspace lsb_carve(void *temp, uint64_t n)
 {
@@ -844,9 +846,10 @@ LsbWorkspace lsb_carve(void *temp, uint64_t n)
     ws.totals = (uint32_t *)(c + spine_bytes(n));
     ws.prefix16 = (uint16_t *)(c + spine_bytes(n) + totals_bytes());
     char *pb = c + spine_bytes(n) + totals_bytes() + prefix16_bytes(n);
-    ws.cc = (uint32_t *)pb;
-    ws.sc = (uint64_t *)(pb + cc_bytes(n));
-    ws.ptotals = (uint32_t *)(pb + cc_bytes(n) + sc_bytes(n));
+    const bool pe = pipe_enabled();
+    ws.cc = pe ? (uint32_t *)pb : nullptr;
+    ws.sc = pe ? (uint64_t *)(pb + cc_bytes(n)) : nullptr;
+    ws.ptotals = (uint32_t *)(pb + (pe ? cc_bytes(n) + sc_bytes(n) : 0));
     ws.error_word = ws.ptotals + 5 * RADIX;
     return ws;
 }

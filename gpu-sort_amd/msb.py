@@ -33,6 +33,10 @@ def rdxsrt_unstable_sort(dev_keys, dev_values, key_count, dev_sorted_keys_out, d
     dm = pre_allocated_dm
     if dm is None:
         dm = torch.empty(max(need, 1), dtype=torch.uint8, device=dev_keys.device)
+        if stream is not None and not synchronize:
+            # allocated on torch's CURRENT stream, used on `stream`, dropped when this function returns: tell the
+            # caching allocator, or it may hand the block to the next allocation while the sort still runs in it
+            dm.record_stream(stream)
     sk, sv = C.c_void_p(), C.c_void_p()
     err = lib.gs_msb_sort_u32(dm.data_ptr(), dm.numel(), dev_keys.data_ptr(),
                               dev_values.data_ptr() if has_values else None, key_count,

@@ -365,15 +365,9 @@ class ShardedSorter:
                         ins_v.append(self.part_v[start + s0:start + s1])
                         outs_v.append(self.recv_v[o + r0:o + r1])
                     o += c
-                try:
-                    w.append(_all_to_all_lists(outs_k, ins_k, self.group))
-                except (RuntimeError, NotImplementedError):
-                    if g != 0 or q != 0:
-                        raise
-                    # a backend without the list form of all_to_all (argument checking fails before anything is
-                    # enqueued, and on every rank alike): one collective from now on
-                    self.groups = 1
-                    return self._sort_msb(keys, vals)
+                # an error here propagates: a rank that changed its collective sequence on its own (a retry in another
+                # form) would leave its peers waiting in this one
+                w.append(_all_to_all_lists(outs_k, ins_k, self.group))
                 if self.pairs:
                     w.append(_all_to_all_lists(outs_v, ins_v, self.group))
             works.append(w)

@@ -23,6 +23,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <cstdio>
 #include <type_traits>
 
 #include "gpusort.h"
@@ -263,6 +264,7 @@ struct RDXSRT_GPUDataManager {
         bytes = gs_msb_temp_bytes(key_count, has_values ? 1 : 0);
         if (hipMalloc(&d_temp, bytes ? bytes : 1) != hipSuccess) { d_temp = nullptr; bytes = 0; }
     }
+    bool ok() const { return d_temp != nullptr; }   // false: the allocation failed; a sort with it returns {nullptr, nullptr}
     ~RDXSRT_GPUDataManager() { if (d_temp) (void)hipFree(d_temp); }
     RDXSRT_GPUDataManager(const RDXSRT_GPUDataManager &) = delete;
     RDXSRT_GPUDataManager &operator=(const RDXSRT_GPUDataManager &) = delete;
@@ -270,7 +272,15 @@ struct RDXSRT_GPUDataManager {
 
 // Ascending, unstable; synchronous like the reference (gpu_radix_sort.h:489-491); dev_values == NULL
 // (ValueT = NullType) sorts keys only (msb/src/test.cu:53).  Result pointers are returned and, for
-// 32-bit keys, are the caller's input arrays.
+// 32-bit keys, are the caller's input arrays.  The reference's signature has no error channel; a failure here
+// (scratch allocation, a pre-allocated manager sized for fewer keys, a failed launch) is reported on stderr and
+// returned as {nullptr, nullptr} -- never as pointers to unsorted data.
+namespace gpusort {
+inline void report_failure(const char *what, int err)
+{
+    std::fprintf(stderr, "gpusort: %s failed: hipError %d (%s)\n", what, err, gs_error_string(err));
+}
+}  // namespace gpusort
 template <typename KeyT, typename ValueT, typename IndexT = unsigned int>
 RDXSRT_SortedSequence<KeyT, ValueT> rdxsrt_unstable_sort(KeyT *dev_keys, ValueT *dev_values, IndexT key_count,
                                                          KeyT *dev_sorted_keys_out, ValueT *dev_sorted_values_out,
@@ -290,23 +300,35 @@ RDXSRT_SortedSequence<KeyT, ValueT> rdxsrt_unstable_sort(KeyT *dev_keys, ValueT 
         void *temp = nullptr;
         void *k2[2] = {dev_keys, dev_sorted_keys_out}, *v2[2] = {dev_values, dev_sorted_values_out};
         int sel = 0;
-        if (hipMalloc(&temp, tb ? tb : 1) == hipSuccess) {
-            (void)gs_lsb_sort_wide(temp, tb, k2, pairs ? v2 : nullptr, &sel, (uint64_t)key_count, (int)sizeof(KeyT), vb, 0,
-                                   8 * (int)sizeof(KeyT), 0, gpusort::KeyTraits<KeyT>::type, stream);
-            (void)hipStreamSynchronize(stream);
-            (void)hipFree(temp);
+        int err = (int)hipMalloc(&temp, tb ? tb : 1);
+        if (err != 0) {
+            gpusort::report_failure("rdxsrt_unstable_sort: scratch allocation", err);
+            return RDXSRT_SortedSequence<KeyT, ValueT>{nullptr, nullptr};
+        }
+        err = gs_lsb_sort_wide(temp, tb, k2, pairs ? v2 : nullptr, &sel, (uint64_t)key_count, (int)sizeof(KeyT), vb, 0,
+                               8 * (int)sizeof(KeyT), 0, gpusort::KeyTraits<KeyT>::type, stream);
+        if (err == 0) err = (int)hipStreamSynchronize(stream);
+        (void)hipFree(temp);
+        if (err != 0) {
+            gpusort::report_failure("rdxsrt_unstable_sort (64-bit path)", err);
+            return RDXSRT_SortedSequence<KeyT, ValueT>{nullptr, nullptr};
         }
         return RDXSRT_SortedSequence<KeyT, ValueT>{reinterpret_cast<KeyT *>(k2[sel]),
                                                    pairs ? reinterpret_cast<ValueT *>(v2[sel]) : nullptr};
     } else {
     RDXSRT_GPUDataManager *dm = pre_allocated_dm ? pre_allocated_dm : new RDXSRT_GPUDataManager((uint64_t)key_count, pairs);
     uint32_t *sk = nullptr, *sv = nullptr;
-    (void)gs_msb_sort_u32(dm->d_temp, dm->bytes, reinterpret_cast<uint32_t *>(dev_keys),
-                          pairs ? reinterpret_cast<uint32_t *>(dev_values) : nullptr, (uint64_t)key_count,
-                          reinterpret_cast<uint32_t *>(dev_sorted_keys_out),
-                          pairs ? reinterpret_cast<uint32_t *>(dev_sorted_values_out) : nullptr, &sk, &sv,
-                          gpusort::KeyTraits<KeyT>::type, stream, 1);
+    const int err = dm->ok() ? gs_msb_sort_u32(dm->d_temp, dm->bytes, reinterpret_cast<uint32_t *>(dev_keys),
+                                               pairs ? reinterpret_cast<uint32_t *>(dev_values) : nullptr, (uint64_t)key_count,
+                                               reinterpret_cast<uint32_t *>(dev_sorted_keys_out),
+                                               pairs ? reinterpret_cast<uint32_t *>(dev_sorted_values_out) : nullptr, &sk, &sv,
+                                               gpusort::KeyTraits<KeyT>::type, stream, 1)
+                             : (int)hipErrorOutOfMemory;
     if (!pre_allocated_dm) delete dm;
+    if (err != 0) {
+        gpusort::report_failure(err == (int)hipErrorOutOfMemory ? "rdxsrt_unstable_sort: scratch allocation" : "rdxsrt_unstable_sort", err);
+        return RDXSRT_SortedSequence<KeyT, ValueT>{nullptr, nullptr};
+    }
     return RDXSRT_SortedSequence<KeyT, ValueT>{reinterpret_cast<KeyT *>(sk), reinterpret_cast<ValueT *>(sv)};
     }
 }

@@ -93,3 +93,18 @@ def test_package_import_brings_torch_in_before_the_library():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "order ok" in out.stdout, out.stderr[-2000:]
     assert "torch fully imported at load: True" in out.stdout, out.stdout
+
+
+def test_shim_reports_failures_instead_of_returning_unsorted_data():
+    """rdxsrt_unstable_sort's shim must not return the input pointers when the scratch allocation (or the
+    sort) failed.  No GPU here, so every allocation fails: the result must be {nullptr, nullptr} and stderr must say why."""
+    import subprocess
+    exe = os.path.join(ROOT, "gpu-sort_amd", "drivers", "shim_errors")
+    if not os.path.exists(exe):
+        pytest.skip("drivers not built (run __graft_entry__.build())")
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the no-device path needs a box without a GPU")
+    out = subprocess.run([exe, "nodevice"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+    assert out.stderr.count("gpusort: rdxsrt_unstable_sort") == 3

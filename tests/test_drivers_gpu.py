@@ -67,3 +67,9 @@ def test_lsb_types_driver_all_type_pairs():
     out = _run(["lsb_types", "200003"])
     assert out[-1] == "ALL CORRECT" and not any("FAIL" in line for line in out)
     assert sum(line.endswith(": CORRECT") for line in out) > 7 * 9
+
+
+def test_shim_too_small_data_manager_yields_null():
+    """A pre-allocated RDXSRT_GPUDataManager sized for fewer keys: {nullptr, nullptr}, not the unsorted input."""
+    out = _run(["shim_errors", "gpu"])
+    assert out[-1] == "OK"

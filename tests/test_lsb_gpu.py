@@ -269,33 +269,40 @@ def test_no_overwrite_mode(gs, cuda, oracle, begin_bit, end_bit, desc):
     assert np.array_equal(to_u32(kin), keys)
 
 
-def test_single_sweep_mode_matches(cuda, oracle, tmp_path):
-    """GS_LSB_MODE=fused (one histogram kernel + look-back scatter per pass, experimental) is bit-exact too.
-    The mode is read once per process, so it runs in a child process."""
+def test_one_launch_pass_mode_matches(cuda, oracle, tmp_path):
+    """GS_LSB_MODE=pipe (every pass after the first as ONE launch: upsweep / scanner / downsweep roles that hand their
+    results over inside the launch; opt-in) is bit-exact too, and none of its bounded waits
+    gave up.  The mode and the size threshold are read once per process, so it runs in a child process."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = r'''
-import sys, numpy as np, torch
+import sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, %r)
 import gpu_sort_amd as gs
 from oracle import oracle as O
 dev = torch.device("cuda:0")
-for n in (8192, 100003, (1 << 22) + 77):
+for n in (17409, 65536, 100003, 8192 * 64 * 8 + 5, (1 << 22) + 77):
     keys = O.cub_random_keys(n, 3); vals = O.gen_enumerated(n)
-    for desc in (False, True):
+    for desc, bb, eb in ((False, 0, 32), (True, 0, 32), (False, 3, 29), (True, 8, 24)):
         dk = gs.DoubleBuffer(torch.from_numpy(keys.view(np.int32).copy()).to(dev), torch.empty(n, dtype=torch.int32, device=dev))
         dv = gs.DoubleBuffer(torch.from_numpy(vals.view(np.int32).copy()).to(dev), torch.empty(n, dtype=torch.int32, device=dev))
         fn = gs.DeviceRadixSort.SortPairsDescending if desc else gs.DeviceRadixSort.SortPairs
         nb = fn(None, 0, dk, dv, n); temp = torch.zeros(nb, dtype=torch.uint8, device=dev)
-        fn(temp, nb, dk, dv, n, key_type=gs.GS_KEY_U32); torch.cuda.synchronize()
-        ek, ev = O.lsb_sort_pairs(keys, vals, descending=desc)
+        fn(temp, nb, dk, dv, n, bb, eb, key_type=gs.GS_KEY_U32); torch.cuda.synchronize()
+        st = C.c_uint32(7)
+        assert gs.lib.gs_lsb_pipe_status(temp.data_ptr(), n, C.byref(st), None) == 0 and st.value == 0, st.value
+        ek, ev = O.lsb_sort_pairs(keys, vals, bb, eb, desc)
         assert np.array_equal(dk.Current().cpu().numpy().view(np.uint32), ek)
         assert np.array_equal(dv.Current().cpu().numpy().view(np.uint32), ev)
-print("fused ok")
+        kk = gs.DoubleBuffer(torch.from_numpy(keys.view(np.int32).copy()).to(dev), torch.empty(n, dtype=torch.int32, device=dev))
+        fk = gs.DeviceRadixSort.SortKeysDescending if desc else gs.DeviceRadixSort.SortKeys
+        fk(temp, nb, kk, n, bb, eb, key_type=gs.GS_KEY_U32); torch.cuda.synchronize()
+        assert np.array_equal(kk.Current().cpu().numpy().view(np.uint32), O.lsb_sort_keys(keys, bb, eb, desc))
+print("pipe ok")
 ''' % root
-    env = dict(os.environ, GS_LSB_MODE="fused")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "fused ok" in out.stdout, out.stderr[-2000:]
+    env = dict(os.environ, GS_LSB_MODE="pipe", GS_LSB_PIPE_MIN_TILES="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "pipe ok" in out.stdout, out.stderr[-2000:]
 
 
 @pytest.mark.parametrize("algo", ["lsb", "lsb_pairs", "lsb_f32_desc", "msb", "msb_pairs"])
