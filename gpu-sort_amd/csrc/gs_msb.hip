@@ -65,8 +65,25 @@ struct MsbLevel {
     uint32_t task_count[MSB_NCLASS];     // local-sort tasks emitted by this level's classification
     uint32_t flagged;                    // != 0: the one-pass local sort left tasks to the general kernel (a plain store:
                                          // thousands of atomics on one word would cost a millisecond)
-    uint32_t pad;
+    uint32_t pivot_buckets;              // buckets of this level finished by the heavy-hitter path (see MsbPivot)
+    unsigned long long pivot_keys;       // keys in them
+    unsigned long long pad;
 };
+// Heavy hitters (skewed inputs: BASELINE configs[3], Zipf).  A bucket in which ONE key value holds at least half of the
+// keys -- and the keys below and above it each fit a local sort -- is finished where it stands instead of being
+// partitioned byte by byte down to the last level (the reference moves such keys at every remaining pass, only its
+// shared-memory atomics are spared: cuda_radix_sort.h:438-441; CUB skips a pass only when ONE digit holds everything,
+// agent_radix_sort_downsweep.cuh:694-707):
+//   expand    picks the candidate value (majority of three samples of the bucket),
+//   upsweep   counts the keys equal to / below it next to the digit histogram,
+//   classify  decides (eq >= size / 2, less and greater <= the largest local sort) and emits the two stranger ranges as
+//             local-sort tasks,
+//   scatter   such a bucket's tiles move ONLY the strangers (to their final ranges in the level's destination buffer)
+//             and write the value over the middle range of the result buffer (in place where the bucket already
+//             lies in the result buffer: only the slots a stranger held are touched).
+// 8 B/key (upsweep read + tile read; + 4 B/key of writes where the bucket lies in the other buffer) once, instead of
+// 12 B/key per remaining level.
+struct MsbPivot { uint32_t cand, eq, less, flag, cur_less, cur_greater, examine, pad1; };   // examine: the samples made it a candidate
 
 // A level is partitioned like an LSB pass over its tiles (no atomics, deterministic): the tiles of
 // all its buckets are numbered consecutively, 8 consecutive tiles form a chunk,
@@ -83,6 +100,7 @@ struct MsbWs {
     uint16_t *prefix16;                  // [max_tiles][256]
     MsbTask *tasks[MSB_NCLASS];
     MsbPiece *pieces;                    // [extra_pieces] (gs_msb_finish_u32 only)
+    MsbPivot *pivots;                    // [max_buckets] heavy-hitter state of the current level's buckets
     // capacities of the lists above.  The sizing makes them sufficient; all the same every device-side append and
     // every reader of a device-side count is bounded by them, so that a wrong count (a bug) gives a wrong result a
     // test can catch instead of an out-of-bounds access (a GPU memory fault can take the whole node down)
@@ -100,7 +118,8 @@ static inline uint32_t msb_max_tasks(uint64_t n, bool has_values, uint32_t extra
 {
     // a task is either >= MSB_MERGE keys or is followed by something that did not fit: <= 2n/MERGE,
     // plus up to 256 per partitioned bucket
-    return (uint32_t)(2 * n / MSB_MERGE) + msb_max_buckets(n, has_values, extra) + 2 * RADIX + extra_tasks;
+    // (+ two stranger ranges per heavy-hitter bucket)
+    return (uint32_t)(2 * n / MSB_MERGE) + 3 * msb_max_buckets(n, has_values, extra) + 2 * RADIX + extra_tasks;
 }
 // tiles of a level: n / TILE full ones + one ragged tile per bucket, padded to whole chunks + one spare chunk
 static inline uint32_t msb_max_tiles(uint64_t n, bool has_values, uint32_t extra = 0)
@@ -115,7 +134,7 @@ static size_t msb_ws_bytes(uint64_t n, bool has_values, uint32_t extra = 0, uint
     return align256(5 * sizeof(MsbLevel)) + 2 * align256(mb * sizeof(MsbBucket)) + align256(ml * sizeof(MsbTile)) +
            align256(mb * RADIX * sizeof(uint32_t)) + align256((size_t)RADIX * (ml / MSB_WAVES) * sizeof(uint32_t)) +
            align256(ml * RADIX * sizeof(uint16_t)) + MSB_NCLASS * align256(mt * sizeof(MsbTask)) +
-           align256((size_t)extra * sizeof(MsbPiece));
+           align256((size_t)extra * sizeof(MsbPiece)) + align256(mb * sizeof(MsbPivot));
 }
 static MsbWs msb_carve(void *temp, uint64_t n, bool has_values, uint32_t extra = 0, uint32_t extra_tasks = 0)
 {
@@ -132,7 +151,8 @@ static MsbWs msb_carve(void *temp, uint64_t n, bool has_values, uint32_t extra =
     ws.spine = (uint32_t *)c; c += align256((size_t)RADIX * ws.stride * sizeof(uint32_t));
     ws.prefix16 = (uint16_t *)c; c += align256((size_t)ws.max_tiles * RADIX * sizeof(uint16_t));
     for (int i = 0; i < MSB_NCLASS; ++i) { ws.tasks[i] = (MsbTask *)c; c += align256((size_t)ws.max_tasks * sizeof(MsbTask)); }
-    ws.pieces = (MsbPiece *)c;
+    ws.pieces = (MsbPiece *)c; c += align256((size_t)extra * sizeof(MsbPiece));
+    ws.pivots = (MsbPivot *)c;
     return ws;
 }
 
@@ -158,12 +178,25 @@ __global__ void msb_single_task_kernel(MsbWs ws, uint32_t n, int cls)
 }
 
 // tile records of level L from its bucket list (one block per bucket and step)
-__global__ __launch_bounds__(256) void msb_expand_kernel(MsbWs ws, int L)
+// `pivot_src` != nullptr: also pick the bucket's heavy-hitter candidate from its keys (see MsbPivot)
+__global__ __launch_bounds__(256) void msb_expand_kernel(MsbWs ws, int L, const uint32_t *__restrict__ pivot_src = nullptr)
 {
     uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
     if (nb > ws.max_buckets) nb = ws.max_buckets;
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const MsbBucket B = ws.buckets[L & 1][b];
+        if (pivot_src && threadIdx.x < WAVE) {
+            // candidate = majority of three samples; the bucket is only examined further (the upsweep's per-key
+            // compares cost it a third of its time) if at least 3 of 16 evenly spaced samples agree with it -- a value
+            // holding half of the bucket fails that with probability 0.002, one holding 5 % passes with 0.04
+            const uint32_t q = B.size / 4u;
+            const uint32_t a0 = pivot_src[B.offset + q], a1 = pivot_src[B.offset + 2u * q], a2 = pivot_src[B.offset + 3u * q];
+            const uint32_t cand = (a1 == a2) ? a1 : a0;
+            const uint32_t lane = threadIdx.x;
+            const uint32_t smp = pivot_src[B.offset + (uint32_t)(((unsigned long long)B.size * (2u * (lane & 15u) + 1u)) >> 5)];
+            const uint32_t hits = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(lane < 16u && smp == cand));
+            if (lane == 0) ws.pivots[b] = MsbPivot{cand, 0u, 0u, 0u, 0u, 0u, hits >= 3u ? 1u : 0u, 0u};
+        }
         for (uint32_t t = threadIdx.x; t < B.tiles; t += blockDim.x) {
             const uint32_t lo = B.offset + t * MSB_TILE, left = B.size - t * MSB_TILE;
             if (B.tile_start + t < ws.max_tiles)
@@ -220,7 +253,8 @@ __device__ __forceinline__ uint32_t msb_digit(const DigitSel &ds, const uint8_t 
 
 // M3 as an upsweep: one block per chunk of 8 level tiles, one WAVE per tile (wave-private LDS
 // counters, 32 dword loads in flight per lane: bucket offsets are not 16-byte aligned).
-template <bool REMAP>
+// PIVOT: also count the keys equal to / below the bucket's heavy-hitter candidate (see MsbPivot).
+template <bool REMAP, bool PIVOT = false>
 __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int L, const uint32_t *__restrict__ src, DigitSel ds)
 {
     constexpr int SUB = 4;      // histogram copies per wave, padded rows (see lsb_upsweep_kernel)
@@ -239,9 +273,16 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int 
         if (g < ntiles) {
             const MsbTile T = ws.tiles[g];
             const uint32_t *p = src + T.lo;
+            uint32_t cand = 0, n_eq = 0, n_less = 0;
+            bool examine = false;
+            if (PIVOT) { cand = ws.pivots[T.bucket].cand; examine = ws.pivots[T.bucket].examine != 0u; }
             auto count = [&](uint32_t k) {
                 if (!REMAP && ds.tw_in) k = twiddle_in(k, ds.f32_in, ds.xor_in);
                 hist_add(my, msb_digit<REMAP>(ds, tab, k));
+                if (PIVOT && examine) {   // wave-uniform tallies: one compare per key, the rest is scalar
+                    n_eq += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(k == cand));
+                    n_less += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(k < cand));
+                }
             };
             if (T.valid == (uint32_t)MSB_TILE) {
 #pragma unroll
@@ -267,6 +308,12 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int 
 #pragma unroll
                     for (int u = 0; u < BATCH; ++u)
                         if (j + u * WAVE + lane < T.valid) count(v[u]);
+                }
+            }
+            if (PIVOT && examine) {
+                if (lane == 0) {
+                    if (n_eq) atomicAdd(&ws.pivots[T.bucket].eq, n_eq);
+                    if (n_less) atomicAdd(&ws.pivots[T.bucket].less, n_less);
                 }
             }
         }
@@ -324,7 +371,8 @@ __global__ __launch_bounds__(1024) void msb_scan_kernel(MsbWs ws, int L)
 // LAST (byte 0): only the cursors are needed, the scatter finishes everything.
 // `counts0`: level 0 of the sort reads the LSB pass's digit totals instead
 // (and needs no cursors: the LSB downsweep does that scatter).
-template <bool LAST>
+// PIVOT: a bucket dominated by one key value is finished by the heavy-hitter path instead (see MsbPivot).
+template <bool LAST, bool PIVOT = false>
 __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, const uint32_t *__restrict__ counts0, int nclass)
 {
     __shared__ uint32_t scratch[8];
@@ -339,6 +387,27 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
     const uint32_t rb = 24u - 8u * (uint32_t)L;                  // bits below this level's byte
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const MsbBucket B = ws.buckets[L & 1][b];
+        if (PIVOT) {
+            const MsbPivot P = ws.pivots[b];
+            const uint32_t greater = B.size - P.eq - P.less;
+            if (P.examine && P.eq >= B.size - P.eq && P.less <= cap_max && greater <= cap_max) {   // uniform for the block
+                if (d == 0) {
+                    ws.pivots[b].flag = 1u;
+                    atomicAdd(&ws.level[L].pivot_buckets, 1u);
+                    atomicAdd(&ws.level[L].pivot_keys, (unsigned long long)B.size);
+                    // the strangers share the bucket's upper bytes only: their tasks sort this level's byte too
+                    const uint32_t offs[2] = {B.offset, B.offset + P.less + P.eq}, sizes[2] = {P.less, greater};
+                    for (int q = 0; q < 2; ++q) {
+                        if (sizes[q] == 0) continue;
+                        int cls = 0;
+                        while (msb_class_cap(cls) < sizes[q]) ++cls;
+                        const uint32_t at = atomicAdd(&ws.level[L].task_count[cls], 1u);
+                        if (at < ws.max_tasks) ws.tasks[cls][at] = MsbTask{offs[q], sizes[q], rb + 8u, 0u};
+                    }
+                }
+                continue;
+            }
+        }
         uint32_t c, e0 = 0;
         if (counts0) {
             c = counts0[d];
@@ -601,13 +670,76 @@ __device__ __forceinline__ void msb_scatter_tile(ScatterSmem<HAS_VALUES, REMAP> 
     }
 }
 
+// One tile of a bucket the heavy-hitter path finishes (keys only; see MsbPivot): strangers go to their final ranges
+// in `other` (the level's destination buffer, where this level's local sorts read), the candidate value goes to the
+// tile's share of the middle range of `result`.  The tile writes `result` only inside its own key range, so the
+// bucket may lie in `result` itself (`in_place`); then only slots that held a stranger need the value -- unless the
+// keys still carry their order-preserving transform, which the stored value must not (`write_all`).
+template <bool FULL>
+__device__ __forceinline__ void msb_pivot_tile(uint32_t *__restrict__ scratch /* LDS, >= 2 * MSB_WAVES + 2 words */,
+                                               MsbPivot *__restrict__ P, const MsbBucket &B, const uint32_t *__restrict__ src_k,
+                                               uint32_t *__restrict__ other, uint32_t *__restrict__ result, uint32_t lo,
+                                               uint32_t valid, int f32_out, uint32_t xor_out, bool write_all)
+{
+    const int lane = lane_id(), w = wave_id();
+    const uint32_t wbase = (uint32_t)w * (WAVE * MSB_KPT) + lane;
+    uint32_t key[MSB_KPT];
+    const uint32_t *pk = src_k + lo;
+#pragma unroll
+    for (int i = 0; i < MSB_KPT; ++i) {
+        const uint32_t idx = wbase + i * WAVE;
+        key[i] = pk[FULL ? idx : (idx < valid ? idx : valid - 1u)];
+    }
+    const uint32_t cand = P->cand, mid_lo = B.offset + P->less, mid_hi = mid_lo + P->eq;
+    const uint32_t cand_out = twiddle_out(cand, f32_out, xor_out);
+    // strangers of the tile: one reservation per side and tile (a level-2 bucket of a Zipf input holds ~8000 of them: one
+    // global atomic per key serialises on two words per bucket -- measured 4.0 ms for the level against 0.83 ms; one
+    // returning atomic per wave instead of the two barriers: 1.3 ms), ranks by ballot
+    uint32_t wl = 0, wg = 0;   // wave-uniform counts
+#pragma unroll
+    for (int i = 0; i < MSB_KPT; ++i) {
+        const bool in = FULL || wbase + i * WAVE < valid;
+        wl += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(in && key[i] < cand));
+        wg += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(in && key[i] > cand));
+    }
+    if (lane == 0) { scratch[w] = wl; scratch[MSB_WAVES + w] = wg; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tl = 0, tg = 0;
+#pragma unroll
+        for (int j = 0; j < MSB_WAVES; ++j) { const uint32_t a = scratch[j], b2 = scratch[MSB_WAVES + j]; scratch[j] = tl; scratch[MSB_WAVES + j] = tg; tl += a; tg += b2; }
+        scratch[2 * MSB_WAVES] = tl ? atomicAdd(&P->cur_less, tl) : 0u;
+        scratch[2 * MSB_WAVES + 1] = tg ? atomicAdd(&P->cur_greater, tg) : 0u;
+    }
+    __syncthreads();
+    uint32_t nl = B.offset + scratch[2 * MSB_WAVES] + scratch[w];                           // next free slot, from the front
+    uint32_t ng = B.offset + B.size - 1u - scratch[2 * MSB_WAVES + 1] - scratch[MSB_WAVES + w];   // from the back
+#pragma unroll
+    for (int i = 0; i < MSB_KPT; ++i) {
+        const uint32_t idx = wbase + i * WAVE;
+        const bool in = FULL || idx < valid;
+        const uint32_t k = key[i], at = lo + idx;
+        const unsigned long long ml = __builtin_amdgcn_ballot_w64(in && k < cand), mg = __builtin_amdgcn_ballot_w64(in && k > cand);
+        if (in) {
+            if (k < cand) other[nl + count_lower_mask(ml)] = k;
+            else if (k > cand) other[ng - count_lower_mask(mg)] = k;
+            if (at >= mid_lo && at < mid_hi && (write_all || k != cand)) result[at] = cand_out;
+        }
+        nl += (uint32_t)__popcll(ml);
+        ng -= (uint32_t)__popcll(mg);
+    }
+}
+
 // FULL = true: one block per level tile, dispatched in order; ragged tiles are skipped.
 // FULL = false: one block per bucket, for its ragged last tile (if any).  Two kernels keep the
 // guarded path's registers out of the hot one (as in the LSB downsweep).
-template <bool HAS_VALUES, bool REMAP, bool TWOUT, bool FULL, bool BIG>
+// PIVOT: tiles of buckets the classification flagged for the heavy-hitter path take msb_pivot_tile (`result_k` = the
+// sort's result buffer, `pivot_f32_out` / `pivot_xor_out` = the key transform to undo in what it stores).
+template <bool HAS_VALUES, bool REMAP, bool TWOUT, bool FULL, bool BIG, bool PIVOT = false>
 __global__ __launch_bounds__(MSB_THREADS, HAS_VALUES ? 4 : 6) void msb_scatter_kernel(
     MsbWs ws, int L, const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k, const uint32_t *__restrict__ src_v,
-    uint32_t *__restrict__ dst_v, DigitSel ds, int f32_out, uint32_t xor_out, int ragged_anywhere)
+    uint32_t *__restrict__ dst_v, DigitSel ds, int f32_out, uint32_t xor_out, int ragged_anywhere,
+    uint32_t *__restrict__ result_k = nullptr, int pivot_f32_out = 0, uint32_t pivot_xor_out = 0u)
 {
     __shared__ __attribute__((aligned(16))) ScatterSmem<HAS_VALUES, REMAP> sm;
     const unsigned long long packed = ws.level[L].packed;
@@ -626,6 +758,13 @@ __global__ __launch_bounds__(MSB_THREADS, HAS_VALUES ? 4 : 6) void msb_scatter_k
     }
     const MsbTile T = ws.tiles[g];
     if (FULL ? T.valid != (uint32_t)MSB_TILE : T.valid == (uint32_t)MSB_TILE) return;
+    if (PIVOT && !HAS_VALUES && ws.pivots[T.bucket].flag) {
+        const MsbBucket B = ws.buckets[L & 1][T.bucket];
+        const bool in_place = result_k == src_k;
+        msb_pivot_tile<FULL>(sm.gbase, ws.pivots + T.bucket, B, src_k, dst_k, result_k, T.lo, T.valid, pivot_f32_out, pivot_xor_out,
+                             !in_place || pivot_f32_out != 0 || pivot_xor_out != 0u);
+        return;
+    }
     if (REMAP) load_remap(ds, sm.tab);
     msb_scatter_tile<HAS_VALUES, REMAP, TWOUT, FULL, BIG>(sm, ds, ws.cursors + (size_t)T.bucket * RADIX, ws.spine + g / MSB_WAVES,
                                                           ws.stride, ws.prefix16 + (size_t)g * RADIX, src_k, dst_k, src_v, dst_v,
@@ -635,11 +774,28 @@ __global__ __launch_bounds__(MSB_THREADS, HAS_VALUES ? 4 : 6) void msb_scatter_k
 template <bool HAS_VALUES, bool REMAP, bool TWOUT>
 static void launch_scatter(const MsbWs &ws, int L, uint32_t tiles_ub, uint32_t buckets_ub, bool big, const uint32_t *sk, uint32_t *dk,
                            const uint32_t *sv, uint32_t *dv, const DigitSel &ds, int f32_out, uint32_t xor_out, hipStream_t s,
-                           bool ragged_anywhere = false)
+                           bool ragged_anywhere = false, uint32_t *pivot_result = nullptr, int pivot_f32_out = 0,
+                           uint32_t pivot_xor_out = 0u)
 {
     const dim3 blk(MSB_THREADS);
     const dim3 rg(ragged_anywhere ? tiles_ub : buckets_ub);
     const int ra = ragged_anywhere ? 1 : 0;
+    if constexpr (!HAS_VALUES && !REMAP) {
+        if (pivot_result) {   // heavy-hitter buckets may exist at this level (keys only)
+            if (big) {
+                hipLaunchKernelGGL((msb_scatter_kernel<false, false, TWOUT, true, true, true>), dim3(tiles_ub), blk, 0, s, ws, L, sk, dk, sv,
+                                   dv, ds, f32_out, xor_out, 0, pivot_result, pivot_f32_out, pivot_xor_out);
+                hipLaunchKernelGGL((msb_scatter_kernel<false, false, TWOUT, false, true, true>), rg, blk, 0, s, ws, L, sk, dk, sv, dv, ds,
+                                   f32_out, xor_out, ra, pivot_result, pivot_f32_out, pivot_xor_out);
+            } else {
+                hipLaunchKernelGGL((msb_scatter_kernel<false, false, TWOUT, true, false, true>), dim3(tiles_ub), blk, 0, s, ws, L, sk, dk, sv,
+                                   dv, ds, f32_out, xor_out, 0, pivot_result, pivot_f32_out, pivot_xor_out);
+                hipLaunchKernelGGL((msb_scatter_kernel<false, false, TWOUT, false, false, true>), rg, blk, 0, s, ws, L, sk, dk, sv, dv, ds,
+                                   f32_out, xor_out, ra, pivot_result, pivot_f32_out, pivot_xor_out);
+            }
+            return;
+        }
+    }
     if (big) {
         hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, REMAP, TWOUT, true, true>), dim3(tiles_ub), blk, 0, s, ws, L, sk, dk, sv, dv,
                            ds, f32_out, xor_out, 0);
@@ -1153,6 +1309,13 @@ static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uin
 // buf[1] (level-1 source) and buf[0] (level-1 destination and final result).  `npieces` != 0:
 // the level-1 buckets and their pieces were written by the host (gs_msb_finish_u32) and the tile
 // records come from the pieces.
+// GS_MSB_PIVOT=0 switches the heavy-hitter path off (A/B measurements; read once per process)
+static inline bool msb_pivot_enabled()
+{
+    static const bool on = [] { const char *e = getenv("GS_MSB_PIVOT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint32_t npieces, uint32_t *const buf_k[2],
                            uint32_t *const buf_v[2], const PassParams &tw, hipStream_t s)
 {
@@ -1166,6 +1329,9 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
         uint32_t *sk = buf_k[L & 1], *dk = buf_k[(L + 1) & 1];
         uint32_t *sv = buf_v[L & 1], *dv = buf_v[(L + 1) & 1];
         const bool in_pieces = npieces != 0 && L == 1;
+        // heavy-hitter path: keys only, buckets in one piece, and not at the last byte (a level-2 bucket's strangers
+        // already cover it)
+        const bool pivot = msb_pivot_enabled() && !pairs && !in_pieces && L <= 2;
         // buckets at level L: <= 256 at level 1, else bounded by size; tiles: n/T + one ragged tile per bucket (piece)
         const uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
         const uint32_t max_tiles = tiles_all + (in_pieces ? npieces : max_b);
@@ -1177,21 +1343,24 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
               hipLaunchKernelGGL(msb_expand_pieces_kernel, dim3(npieces < 4096u ? npieces : 4096u), dim3(256), 0, s, ws, npieces);
           } else {
               const uint32_t eg = max_b < 4096u ? max_b : 4096u;
-              hipLaunchKernelGGL(msb_expand_kernel, dim3(eg), dim3(256), 0, s, ws, L);
+              hipLaunchKernelGGL(msb_expand_kernel, dim3(eg), dim3(256), 0, s, ws, L, pivot ? (const uint32_t *)sk : (const uint32_t *)nullptr);
           }
           const uint32_t hg_ub = max_tiles / MSB_WAVES + 1;                 // one block per chunk
           const uint32_t hg = hg_ub < MSB_MAX_GRID ? hg_ub : MSB_MAX_GRID;
-          hipLaunchKernelGGL(msb_upsweep_kernel<false>, dim3(hg), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, dsel);
+          if (pivot) hipLaunchKernelGGL((msb_upsweep_kernel<false, true>), dim3(hg), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, dsel);
+          else hipLaunchKernelGGL((msb_upsweep_kernel<false, false>), dim3(hg), dim3(MSB_THREADS), 0, s, ws, L, (const uint32_t *)sk, dsel);
           hipLaunchKernelGGL(msb_scan_kernel, dim3(RADIX), dim3(1024), 0, s, ws, L); }
         { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
           const uint32_t cg = max_b < 4096u ? max_b : 4096u;
-          if (last) hipLaunchKernelGGL(msb_classify_kernel<true>, dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass);
-          else hipLaunchKernelGGL(msb_classify_kernel<false>, dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass); }
+          if (last) hipLaunchKernelGGL((msb_classify_kernel<true, false>), dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass);
+          else if (pivot) hipLaunchKernelGGL((msb_classify_kernel<false, true>), dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass);
+          else hipLaunchKernelGGL((msb_classify_kernel<false, false>), dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass); }
         { KernelTimer kt(GS_K_MSB_PARTITION, s);
           const bool big = num_items > (1ull << 30);
           const uint32_t *svc = pairs ? (const uint32_t *)sv : (const uint32_t *)nullptr;
           uint32_t *dvc = pairs ? dv : (uint32_t *)nullptr;
-#define GS_SC(HV, TW) launch_scatter<HV, false, TW>(ws, L, max_tiles, max_b, big, (const uint32_t *)sk, dk, svc, dvc, dsel, tw.f32_out, tw.xor_out, s, in_pieces)
+#define GS_SC(HV, TW) launch_scatter<HV, false, TW>(ws, L, max_tiles, max_b, big, (const uint32_t *)sk, dk, svc, dvc, dsel, tw.f32_out, tw.xor_out, s, in_pieces, \
+                                                  pivot ? d_keys : (uint32_t *)nullptr, tw.f32_out, tw.xor_out)
           if (pairs) { if (last) GS_SC(true, true); else GS_SC(true, false); }
           else { if (last) GS_SC(false, true); else GS_SC(false, false); }
 #undef GS_SC

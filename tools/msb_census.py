@@ -19,9 +19,10 @@ with gs.KernelProfile() as prof:
     gs.rdxsrt_unstable_sort(a, va, n, b, vb, pre_allocated_dm=temp)
     torch.cuda.synchronize()
 off = (gs.lib.gs_lsb_temp_bytes(n, int(pairs)) + 255) // 256 * 256
-raw = temp[off: off + 5 * 32].cpu().numpy().tobytes()
+raw = temp[off: off + 5 * 48].cpu().numpy().tobytes()
 print({k: round(v[0], 3) for k, v in prof.read().items()})
 for L in range(4):
-    packed, t0, t1, t2, t3, flagged, _ = struct.unpack_from("<Q6I", raw, L * 32)
+    packed, t0, t1, t2, t3, flagged, pb, pk, _ = struct.unpack_from("<Q6IQQ", raw, L * 48)
     print(f"level {L}: buckets {packed >> 32:7d}  tiles {packed & 0xffffffff:8d} ({(packed & 0xffffffff) * 8192 / n:6.1%} of the keys)  "
-          f"tasks per class {[t0, t1, t2, t3]}  tasks left to the general plan: {"yes" if flagged else "no"}")
+          f"heavy-hitter buckets {pb} ({pk / n:6.1%} of the keys)  "
+          f"tasks per class {[t0, t1, t2, t3]}  tasks left to the general plan: {'yes' if flagged else 'no'}")
