@@ -294,7 +294,28 @@ def main():
         ms_per_step = elapsed / steps * 1e3
         dom = "lsb_downsweep" if "lsb_downsweep" in kernels else ("msb_partition" if "msb_partition" in kernels else None)
         roofline = None
-        if dom and dom in kernels:
+        whole = None
+        census = None
+        if algo == "msb" and not sharded_path:
+            # the MSB path's bytes are data-dependent -> from the census of the last timed sort (what every
+            # level partitioned / handed to local sorts); the roofline entry is the kernel group that took the most time
+            from gpu_sort_amd.msb import msb_census, msb_algorithmic_bytes
+            census = msb_census(temp, n, args.pairs)
+            by = msb_algorithmic_bytes(census, n, args.pairs)
+            per_sort = {k: kernels[k][0] / steps for k in by if k in kernels}
+            dom = max(per_sort, key=per_sort.get)
+            achieved = by[dom] / (per_sort[dom] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_sort": by[dom], "ms_per_sort": round(per_sort[dom], 4),
+                        "launches_per_sort": kernels[dom][1] // steps,
+                        "all_kernel_groups": {k: {"algorithmic_bytes": by[k], "ms_per_sort": round(per_sort[k], 4),
+                                                  "GBps": round(by[k] / (per_sort[k] * 1e-3) / 1e9, 1)} for k in per_sort}}
+            tot = sum(by.values())
+            gbs = tot / (ms_per_step * 1e-3) / 1e9
+            whole = {"algorithmic_bytes_per_key": round(tot / n, 2), "achieved_GBps": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+                     "census": [{k: c[k] for k in ("buckets", "keys", "pivot_buckets", "pivot_keys", "task_keys", "tasks")} for c in census]}
+        elif dom and dom in kernels:
             ms, cnt = kernels[dom]
             avg_ms = ms / cnt
             # keys per launch: the whole array on one GPU; a rank's received slice (~n) when sharded
@@ -308,8 +329,7 @@ def main():
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 4),
                         "launches": cnt}
-        whole = None
-        if algo == "lsb" and world == 1:
+        if algo == "lsb" and world == 1 and not sharded_path:
             gbs = LSB_BYTES_PER_KEY[args.pairs] * n / (ms_per_step * 1e-3) / 1e9
             whole = {"algorithmic_bytes_per_key": LSB_BYTES_PER_KEY[args.pairs], "achieved_GBps": round(gbs, 1),
                      "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),

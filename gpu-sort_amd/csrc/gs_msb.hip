@@ -31,6 +31,7 @@
 #include <new>
 #include "gs_lsb.hpp"
 #include <type_traits>
+#include <vector>
 #include <cstdlib>
 
 namespace gs {
@@ -67,6 +68,8 @@ struct MsbLevel {
                                          // thousands of atomics on one word would cost a millisecond)
     uint32_t pivot_buckets;              // buckets of this level finished by the heavy-hitter path (see MsbPivot)
     unsigned long long pivot_keys;       // keys in them
+    unsigned long long keys;             // keys in this level's buckets                 } census only
+    unsigned long long task_keys;        // keys in the tasks this level's classification emitted   } (gs_msb_census)
     unsigned long long pad;
 };
 // Heavy hitters (skewed inputs: BASELINE configs[3], Zipf).  A bucket in which ONE key value holds at least half of the
@@ -162,7 +165,7 @@ __global__ void msb_init_kernel(MsbWs ws, uint32_t n)
     const int t = threadIdx.x;
     if (t < 5) {
         MsbLevel z{};
-        if (t == 0) z.packed = (1ull << 32) | msb_tiles_of(n);
+        if (t == 0) { z.packed = (1ull << 32) | msb_tiles_of(n); z.keys = n; }
         ws.level[t] = z;
     }
     if (t == 0) ws.buckets[0][0] = MsbBucket{0u, n, 0u, msb_tiles_of(n)};
@@ -365,8 +368,8 @@ __global__ __launch_bounds__(1024) void msb_scan_kernel(MsbWs ws, int L)
 //   empty                      -> nothing
 //   > largest local capacity   -> bucket of level L+1 (partitioned on the next byte)
 //   otherwise                  -> local-sort task; adjacent sub-buckets are merged
-//                                 greedily while the running sum is < MSB_MERGE and
-//                                 still fits (a merged task also re-sorts this byte).
+//                                 greedily while the sum stays < MSB_MERGE
+//                                 (a merged task also re-sorts this byte).
 // The counts are differences of the scanned upsweep: E(g, d) over the bucket's tile range.
 // LAST (byte 0): only the cursors are needed, the scatter finishes everything.
 // `counts0`: level 0 of the sort reads the LSB pass's digit totals instead
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t s_cnt[RADIX], s_abs[RADIX], s_task[RADIX], s_nsub[RADIX];
     __shared__ uint8_t s_large[RADIX];
-    __shared__ uint32_t s_tot[2], s_ccnt[MSB_NCLASS], s_cbase[MSB_NCLASS];
+    __shared__ uint32_t s_tot[2], s_ccnt[MSB_NCLASS], s_cbase[MSB_NCLASS], s_ksum[2];
     __shared__ unsigned long long s_base64;
     uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
     if (nb > ws.max_buckets) nb = ws.max_buckets;              // never (see MsbWs)
@@ -395,6 +398,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
                     ws.pivots[b].flag = 1u;
                     atomicAdd(&ws.level[L].pivot_buckets, 1u);
                     atomicAdd(&ws.level[L].pivot_keys, (unsigned long long)B.size);
+                    atomicAdd(&ws.level[L].task_keys, (unsigned long long)(P.less + greater));
                     // the strangers share the bucket's upper bytes only: their tasks sort this level's byte too
                     const uint32_t offs[2] = {B.offset, B.offset + P.less + P.eq}, sizes[2] = {P.less, greater};
                     for (int q = 0; q < 2; ++q) {
@@ -423,6 +427,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
         if (LAST) continue;
         s_cnt[d] = c; s_abs[d] = abs; s_task[d] = 0; s_nsub[d] = 0; s_large[d] = 0;
         if (d < MSB_NCLASS) s_ccnt[d] = 0;
+        if (d < 2) s_ksum[d] = 0;
         __syncthreads();
         if (d == 0) {
             int run_start = -1;
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
                     s_large[q] = 1;
                     continue;
                 }
-                if (run_start >= 0 && run_sum < MSB_MERGE && run_sum + cq <= cap_max) {
+                if (run_start >= 0 && run_sum + cq < MSB_MERGE) {   // the reference's test (cuda_radix_sort.h:1084): sum AFTER adding
                     run_sum += cq; ++run_nsub;
                 } else {
                     if (run_start >= 0) { s_task[run_start] = run_sum; s_nsub[run_start] = run_nsub; }
@@ -458,11 +463,18 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
         const uint32_t tidx = block_exclusive_scan_256(tiles, scratch, &s_tot[1]);
         uint32_t task_local = 0;
         if (tsize) task_local = atomicAdd(&s_ccnt[cls], 1u);          // LDS
+        {   // census sums (a bucket holds < 2^32 keys)
+            const uint32_t kl = wave_reduce_sum(is_large ? c : 0u), kt = wave_reduce_sum(tsize);
+            if (lane_id() == 0) { if (kl) atomicAdd(&s_ksum[0], kl); if (kt) atomicAdd(&s_ksum[1], kt); }
+        }
         __syncthreads();
         if (d == 0) {
             unsigned long long old = 0;
             if (s_tot[0]) old = atomicAdd(&ws.level[L + 1].packed, ((unsigned long long)s_tot[0] << 32) | s_tot[1]);
             s_base64 = old;
+            // census: keys passed on to the next level / handed to local sorts
+            if (s_ksum[0]) atomicAdd(&ws.level[L + 1].keys, (unsigned long long)s_ksum[0]);
+            if (s_ksum[1]) atomicAdd(&ws.level[L].task_keys, (unsigned long long)s_ksum[1]);
         }
         if (d < MSB_NCLASS) {
             const uint32_t k = s_ccnt[d];
@@ -1316,8 +1328,11 @@ static inline bool msb_pivot_enabled()
     return on;
 }
 
+// `stop_level` (test access, gs_msb_classify_upto): return right after that level's classification; `allow_pivot` = false
+// keeps the heavy-hitter path off whatever the environment says.
 static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint32_t npieces, uint32_t *const buf_k[2],
-                           uint32_t *const buf_v[2], const PassParams &tw, hipStream_t s)
+                           uint32_t *const buf_v[2], const PassParams &tw, hipStream_t s, int stop_level = 99,
+                           bool allow_pivot = true)
 {
     const int nclass = msb_num_classes(pairs);
     const uint32_t tiles_all = (uint32_t)((num_items + MSB_TILE - 1) / MSB_TILE);
@@ -1331,7 +1346,7 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
         const bool in_pieces = npieces != 0 && L == 1;
         // heavy-hitter path: keys only, buckets in one piece, and not at the last byte (a level-2 bucket's strangers
         // already cover it)
-        const bool pivot = msb_pivot_enabled() && !pairs && !in_pieces && L <= 2;
+        const bool pivot = allow_pivot && msb_pivot_enabled() && !pairs && !in_pieces && L <= 2;
         // buckets at level L: <= 256 at level 1, else bounded by size; tiles: n/T + one ragged tile per bucket (piece)
         const uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
         const uint32_t max_tiles = tiles_all + (in_pieces ? npieces : max_b);
@@ -1355,6 +1370,7 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
           if (last) hipLaunchKernelGGL((msb_classify_kernel<true, false>), dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass);
           else if (pivot) hipLaunchKernelGGL((msb_classify_kernel<false, true>), dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass);
           else hipLaunchKernelGGL((msb_classify_kernel<false, false>), dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass); }
+        if (L == stop_level) return;
         { KernelTimer kt(GS_K_MSB_PARTITION, s);
           const bool big = num_items > (1ull << 30);
           const uint32_t *svc = pairs ? (const uint32_t *)sv : (const uint32_t *)nullptr;
@@ -1420,9 +1436,9 @@ size_t gs_msb_temp_bytes(uint64_t num_items, int has_values)
     return align256(lsb_temp_bytes(num_items)) + msb_ws_bytes(num_items, has_values != 0);
 }
 
-int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t *d_vals, uint64_t num_items,
-                    uint32_t *d_keys_alt, uint32_t *d_vals_alt, uint32_t **d_sorted_keys, uint32_t **d_sorted_vals,
-                    int key_type, void *stream, int synchronize)
+static int msb_sort_impl(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t *d_vals, uint64_t num_items,
+                         uint32_t *d_keys_alt, uint32_t *d_vals_alt, uint32_t **d_sorted_keys, uint32_t **d_sorted_vals,
+                         int key_type, void *stream, int synchronize, int stop_level, bool allow_pivot)
 {
     GS_CLEAR_STALE_ERROR();
     if (num_items >= (1ull << 32)) return hipErrorInvalidValue;
@@ -1464,6 +1480,7 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
         if ((e = lsb_scan(lw.spine, lw.totals, p0.grid, s))) return e;
         { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
           hipLaunchKernelGGL(msb_classify_kernel<false>, dim3(1), dim3(256), 0, s, ws, 0, (const uint32_t *)lw.totals, nclass); }
+        if (stop_level == 0) { const int e0 = (int)hipGetLastError(); return e0 ? e0 : (synchronize ? (int)hipStreamSynchronize(s) : 0); }
         if ((e = lsb_downsweep(d_keys, d_keys_alt, d_vals, d_vals_alt, lw.spine, lw.prefix16, lw.totals, p0, s))) return e;
         // upper bounds of what a level can hold (surplus blocks exit immediately)
         const uint32_t max_tasks_lvl = ws.max_tasks;
@@ -1471,12 +1488,93 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t 
         if (pairs) launch_local_sorts<true>(ws, 0, task_grid0, d_keys_alt, d_keys, d_vals_alt, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24, num_items);
         else launch_local_sorts<false>(ws, 0, task_grid0, d_keys_alt, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24, num_items);
 
-        msb_run_levels(ws, num_items, pairs, /*pieces=*/0u, buf_k, buf_v, tw, s);
+        msb_run_levels(ws, num_items, pairs, /*pieces=*/0u, buf_k, buf_v, tw, s, stop_level, allow_pivot);
     }
     int err = (int)hipGetLastError();
     if (err) return err;
     if (synchronize) err = (int)hipStreamSynchronize(s);
     return err;
+}
+
+int gs_msb_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t *d_vals, uint64_t num_items,
+                    uint32_t *d_keys_alt, uint32_t *d_vals_alt, uint32_t **d_sorted_keys, uint32_t **d_sorted_vals,
+                    int key_type, void *stream, int synchronize)
+{
+    return msb_sort_impl(d_temp, temp_bytes, d_keys, d_vals, num_items, d_keys_alt, d_vals_alt, d_sorted_keys, d_sorted_vals, key_type,
+                         stream, synchronize, 99, true);
+}
+
+int gs_msb_classify_upto(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t *d_keys_alt, uint64_t num_items,
+                         int stop_level, int flags, void *stream)
+{
+    if (stop_level < 0 || stop_level > 2) return hipErrorInvalidValue;
+    if (num_items <= msb_class_cap(msb_num_classes(false) - 1)) return hipErrorInvalidValue;   // such arrays have no levels
+    return msb_sort_impl(d_temp, temp_bytes, d_keys, nullptr, num_items, d_keys_alt, nullptr, nullptr, nullptr, GS_KEY_U32, stream, 1,
+                         stop_level, (flags & 1) == 0);
+}
+
+int gs_msb_census(void *d_temp, uint64_t num_items, int has_values, gs_msb_level_census out[4], void *stream)
+{
+    GS_CLEAR_STALE_ERROR();
+    if (!d_temp || !out || num_items >= (1ull << 32)) return hipErrorInvalidValue;
+    const MsbWs ws = msb_carve((char *)d_temp + align256(lsb_temp_bytes(num_items)), num_items, has_values != 0);
+    MsbLevel lv[4];
+    hipError_t e = hipMemcpyAsync(lv, ws.level, sizeof(lv), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    for (int L = 0; L < 4; ++L) {
+        gs_msb_level_census c{};
+        c.buckets = lv[L].packed >> 32;
+        c.tiles = (uint32_t)lv[L].packed;
+        c.keys = lv[L].keys;
+        c.pivot_buckets = lv[L].pivot_buckets;
+        c.pivot_keys = lv[L].pivot_keys;
+        c.task_keys = lv[L].task_keys;
+        for (int q = 0; q < MSB_NCLASS; ++q) c.tasks[q] = lv[L].task_count[q];
+        c.flagged = lv[L].flagged;
+        out[L] = c;
+    }
+    return hipSuccess;
+}
+
+int gs_msb_read_lists(void *d_temp, uint64_t num_items, int has_values, int level, uint32_t *h_buckets, uint32_t max_buckets,
+                      uint32_t *n_buckets, uint32_t *h_tasks[4], uint32_t max_tasks, uint32_t n_tasks[4], void *stream)
+{
+    GS_CLEAR_STALE_ERROR();
+    if (!d_temp || level < 0 || level > 2 || num_items >= (1ull << 32)) return hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const MsbWs ws = msb_carve((char *)d_temp + align256(lsb_temp_bytes(num_items)), num_items, has_values != 0);
+    MsbLevel lv[4];
+    hipError_t e = hipMemcpyAsync(lv, ws.level, sizeof(lv), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return (int)e;
+    uint32_t nb = (uint32_t)(lv[level + 1].packed >> 32);
+    if (nb > ws.max_buckets) nb = ws.max_buckets;
+    if (n_buckets) *n_buckets = nb;
+    if (h_buckets && nb) {
+        const uint32_t k = nb < max_buckets ? nb : max_buckets;
+        std::vector<MsbBucket> tmp(k);
+        e = hipMemcpyAsync(tmp.data(), ws.buckets[(level + 1) & 1], (size_t)k * sizeof(MsbBucket), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return (int)e;
+        for (uint32_t i = 0; i < k; ++i) { h_buckets[2 * i] = tmp[i].offset; h_buckets[2 * i + 1] = tmp[i].size; }
+    }
+    for (int c = 0; c < MSB_NCLASS; ++c) {
+        uint32_t nt = lv[level].task_count[c];
+        if (nt > ws.max_tasks) nt = ws.max_tasks;
+        if (n_tasks) n_tasks[c] = nt;
+        if (h_tasks && h_tasks[c] && nt) {
+            const uint32_t k = nt < max_tasks ? nt : max_tasks;
+            std::vector<MsbTask> tmp(k);
+            e = hipMemcpyAsync(tmp.data(), ws.tasks[c], (size_t)k * sizeof(MsbTask), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return (int)e;
+            for (uint32_t i = 0; i < k; ++i) {
+                h_tasks[c][3 * i] = tmp[i].offset; h_tasks[c][3 * i + 1] = tmp[i].size; h_tasks[c][3 * i + 2] = tmp[i].sort_bits;
+            }
+        }
+    }
+    return hipSuccess;
 }
 
 // ---- segmented sort (cub::DeviceSegmentedRadixSort, dispatch_radix_sort.cuh:321-432)

@@ -73,3 +73,51 @@ def rdxsrt_unstable_sort_pairs(keys, values, key_count=None, device="cuda"):
     dev_keys_out, dev_values_out = torch.empty_like(dev_keys), torch.empty_like(dev_values)
     seq = rdxsrt_unstable_sort(dev_keys, dev_values, n, dev_keys_out, dev_values_out)
     return seq.sorted_keys.cpu().numpy().view(keys.dtype), seq.sorted_values.cpu().numpy().view(values.dtype)
+
+
+# ---- census and test access to the classification (include/gpusort.h: gs_msb_census, gs_msb_classify_upto, gs_msb_read_lists)
+class _LevelCensus(C.Structure):
+    _fields_ = [("buckets", C.c_uint64), ("tiles", C.c_uint64), ("keys", C.c_uint64), ("pivot_buckets", C.c_uint64),
+                ("pivot_keys", C.c_uint64), ("task_keys", C.c_uint64), ("tasks", C.c_uint32 * 4), ("flagged", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+def msb_census(dm, key_count, has_values=False):
+    """Per-level census of the last rdxsrt_unstable_sort that used the workspace tensor `dm`: a list of 4 dicts."""
+    out = (_LevelCensus * 4)()
+    check(lib.gs_msb_census(dm.data_ptr(), key_count, int(has_values), C.cast(out, C.c_void_p), None), "gs_msb_census")
+    return [{"buckets": int(c.buckets), "tiles": int(c.tiles), "keys": int(c.keys), "pivot_buckets": int(c.pivot_buckets),
+             "pivot_keys": int(c.pivot_keys), "task_keys": int(c.task_keys), "tasks": [int(x) for x in c.tasks],
+             "flagged": int(c.flagged)} for c in out]
+
+
+def msb_algorithmic_bytes(census, key_count, has_values=False):
+    """SURVEY.md 8d for the MSB path, from the census: bytes per kernel group of ONE sort (level 0 = one LSB pass)."""
+    kb, mv = 4, (8 if has_values else 4)            # a key read; a key (+ value) moved = read + write of mv each
+    lv = census[1:4]
+    part = sum(c["keys"] - c["pivot_keys"] for c in lv)
+    return {"lsb_upsweep": kb * key_count, "lsb_downsweep": 2 * mv * key_count,
+            "msb_histogram": kb * sum(c["keys"] for c in lv),
+            "msb_partition": 2 * mv * part + kb * sum(c["pivot_keys"] for c in lv),
+            "msb_local_sort": 2 * mv * sum(c["task_keys"] for c in census)}
+
+
+def msb_classify_upto(dev_keys, dev_keys_alt, key_count, stop_level, pivot=True, dm=None):
+    """Run the sort up to and including the classification of `stop_level` and read its lists back:
+    returns (set of (offset, size) next-level buckets, {class: set of (offset, size, sort_bits)}, workspace)."""
+    need = lib.gs_msb_temp_bytes(key_count, 0)
+    if dm is None:
+        dm = torch.empty(max(need, 1), dtype=torch.uint8, device=dev_keys.device)
+    check(lib.gs_msb_classify_upto(dm.data_ptr(), dm.numel(), dev_keys.data_ptr(), dev_keys_alt.data_ptr(), key_count, stop_level,
+                                   0 if pivot else 1, None), "gs_msb_classify_upto")
+    nb = C.c_uint32(0)
+    nt = (C.c_uint32 * 4)()
+    check(lib.gs_msb_read_lists(dm.data_ptr(), key_count, 0, stop_level, None, 0, C.byref(nb), None, 0, nt, None), "gs_msb_read_lists")
+    hb = np.zeros(2 * max(nb.value, 1), dtype=np.uint32)
+    ht = [np.zeros(3 * max(nt[c], 1), dtype=np.uint32) for c in range(4)]
+    ptrs = (C.POINTER(C.c_uint32) * 4)(*[a.ctypes.data_as(C.POINTER(C.c_uint32)) for a in ht])
+    check(lib.gs_msb_read_lists(dm.data_ptr(), key_count, 0, stop_level, hb.ctypes.data_as(C.c_void_p), nb.value, C.byref(nb), ptrs,
+                                max(max(nt), 1), nt, None), "gs_msb_read_lists")
+    buckets = {(int(hb[2 * i]), int(hb[2 * i + 1])) for i in range(nb.value)}
+    tasks = {c: {(int(ht[c][3 * i]), int(ht[c][3 * i + 1]), int(ht[c][3 * i + 2])) for i in range(nt[c])} for c in range(4)}
+    return buckets, tasks, dm

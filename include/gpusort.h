@@ -148,6 +148,39 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes,
                     uint32_t **d_sorted_keys, uint32_t **d_sorted_vals,
                     int key_type, void *stream, int synchronize);
 
+/* Census of the last gs_msb_sort_u32 that used d_temp (read back after synchronising `stream`): what every level
+ * partitioned and what it handed to local sorts.  SURVEY.md 8d: the MSB path's algorithmic bytes are data-dependent --
+ * "the harness must log the per-pass census and compute bytes from it": level 0 moves every key once (12 B/key), a level
+ * L >= 1 reads its `keys` once for the histogram (4 B/key) and moves the ones outside heavy-hitter buckets (8 B/key;
+ * 16 B/pair), heavy-hitter buckets are read once more (4 B/key), and every key is finished by exactly one local sort
+ * (`task_keys`, 8 B/key; 16 B/pair), by the last level's scatter, or inside a heavy-hitter bucket.                     */
+typedef struct gs_msb_level_census {
+    uint64_t buckets;         /* buckets partitioned at this level (level 0: the whole array)            */
+    uint64_t tiles;           /* their 8192-key tiles                                                     */
+    uint64_t keys;            /* keys in them                                                             */
+    uint64_t pivot_buckets;   /* of those, buckets finished by the heavy-hitter path                      */
+    uint64_t pivot_keys;      /* keys in them                                                             */
+    uint64_t task_keys;       /* keys handed to local sorts by this level's classification                */
+    uint32_t tasks[4];        /* local-sort tasks per size class (2048 / 4608 / 9216 / 17408)             */
+    uint32_t flagged;         /* != 0: some tasks needed the general local-sort plan                      */
+    uint32_t reserved;
+} gs_msb_level_census;
+int gs_msb_census(void *d_temp, uint64_t num_items, int has_values, gs_msb_level_census out[4], void *stream);
+
+/* Test access to the classification (cuda_radix_sort.h:1084-1087,1241-1247,
+ * cuda_radix_sort_config.h:9).  Runs the sort of gs_msb_sort_u32 up to and including the classification of
+ * `stop_level` (0..2; that level's scatter and everything after it do not run, so the arrays hold an intermediate
+ * state) and leaves its lists in the workspace; `flags` bit 0 switches the heavy-hitter path off.
+ * gs_msb_read_lists then copies them out: the buckets the classification passed to level stop_level + 1 as
+ * {offset, size} pairs and the local-sort tasks of every class as {offset, size, sort_bits} triples (in device order,
+ * which is not deterministic: compare as sets).  Counts are returned through n_buckets / n_tasks[4]; at most
+ * max_buckets / max_tasks entries are copied per list.                                                              */
+int gs_msb_classify_upto(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t *d_keys_alt, uint64_t num_items,
+                         int stop_level, int flags, void *stream);
+int gs_msb_read_lists(void *d_temp, uint64_t num_items, int has_values, int level,
+                      uint32_t *h_buckets, uint32_t max_buckets, uint32_t *n_buckets,
+                      uint32_t *h_tasks[4], uint32_t max_tasks, uint32_t n_tasks[4], void *stream);
+
 /* ------------------------------------------------ multi-GPU shard helpers --
  * One process per GPU; the exchange itself (one all-to-all over RCCL/xGMI)
  * is issued by the host between these calls (no reference

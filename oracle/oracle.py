@@ -221,3 +221,107 @@ def time_std_sort_mt(keys, threads=0):
 
 def hardware_threads():
     return lib().orc_hardware_threads()
+
+
+# ---- M4: classification of the MSB levels, restated on the CPU with numpy.
+# What it follows in the reference: a sub-bucket is EMPTY (skipped), NON-LOCAL (more keys than the largest local-sort
+# configuration: it becomes a bucket of the next pass, gpu_radix_sort.h:426-468) or LOCAL; adjacent local sub-buckets are
+# merged while the sum stays below RDXSRT_CFG_MERGE_LOCREC_THRESH = 3000 (cuda_radix_sort.h:1084-1087,
+# cuda_radix_sort_config.h:9) and a merged range is sorted on one more byte (cuda_radix_sort.h:1601: byte - is_merged);
+# every local range goes to the first configuration whose capacity holds it (cuda_radix_sort.h:1241-1247).
+# What differs by design in the build under test and is restated here as built: the local-sort capacities
+# (2048 / 4608 / 9216 / 17408 keys; reference 7-9 configurations up to 9216) and the heavy-hitter rule (no
+# reference counterpart: a bucket in which one value holds at least half of the keys is finished where it stands).
+MSB_CLASS_CAPS = (2048, 4608, 9216, 17408)
+MSB_MERGE = 3000
+
+
+def msb_class_of(size):
+    for c, cap in enumerate(MSB_CLASS_CAPS):
+        if size <= cap:
+            return c
+    raise ValueError(size)
+
+
+def msb_classify_counts(counts, offset, level):
+    """One bucket at `level` (0 = top byte) with its 256 sub-bucket counts, starting at `offset`:
+    returns (next-level buckets [(offset, size)], tasks [(class, offset, size, sort_bits)])."""
+    cap_max, rb = MSB_CLASS_CAPS[-1], 24 - 8 * level
+    buckets, tasks = [], []
+    starts = offset + np.concatenate(([0], np.cumsum(counts[:-1]))).astype(np.int64)
+    run = None                      # [start offset, sum, non-empty sub-buckets]
+
+    def flush():
+        nonlocal run
+        if run is not None:
+            tasks.append((msb_class_of(run[1]), int(run[0]), int(run[1]), rb + (8 if run[2] > 1 else 0)))
+            run = None
+
+    for d in range(256):
+        c = int(counts[d])
+        if c == 0:
+            continue
+        if c > cap_max:
+            flush()
+            buckets.append((int(starts[d]), c))
+            continue
+        if run is not None and run[1] + c < MSB_MERGE:
+            run[1] += c
+            run[2] += 1
+        else:
+            flush()
+            run = [starts[d], c, 1]
+    flush()
+    return buckets, tasks
+
+
+def msb_heavy_hitter(content, cap_max=MSB_CLASS_CAPS[-1]):
+    """The heavy-hitter rule on a bucket's keys in the order they lie on the device: (cand, less, eq) or None."""
+    size = content.size
+    q = size // 4
+    a0, a1, a2 = content[q], content[2 * q], content[3 * q]
+    cand = a1 if a1 == a2 else a0
+    smp = content[[(size * (2 * i + 1)) >> 5 for i in range(16)]]
+    if int((smp == cand).sum()) < 3:
+        return None
+    eq, less = int((content == cand).sum()), int((content < cand).sum())
+    greater = size - eq - less
+    if eq >= size - eq and less <= cap_max and greater <= cap_max:
+        return int(cand), less, eq
+    return None
+
+
+def msb_level_lists(keys, stop_level, pivot=True):
+    """Buckets passed to level stop_level + 1 and local-sort tasks emitted by the classification of `stop_level`, for
+    u32 keys: (set of (offset, size), {class: set of (offset, size, sort_bits)}).  Every partition is stable, so a
+    bucket's keys lie on the device in input order; their offsets are their positions in the sorted array."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint32)
+    level_buckets = [(0, keys.size, keys)]                 # (offset, size, content in device order)
+    for level in range(stop_level + 1):
+        nxt, out_b, out_t = [], set(), {c: set() for c in range(4)}
+        rb = 24 - 8 * level
+        for off, size, content in level_buckets:
+            hh = msb_heavy_hitter(content) if (pivot and level >= 1) else None
+            if hh is not None:
+                cand, less, eq = hh
+                for o, s in ((off, less), (off + less + eq, size - less - eq)):
+                    if s:
+                        out_t[msb_class_of(s)].add((o, s, rb + 8))
+                continue
+            digit = (content >> np.uint32(rb)) & np.uint32(0xff)
+            counts = np.bincount(digit, minlength=256)
+            b, t = msb_classify_counts(counts, off, level)
+            for c, o, s, bits in t:
+                out_t[c].add((o, s, bits))
+            if b:
+                order = np.argsort(digit, kind="stable")
+                by_digit = content[order]
+                starts = np.concatenate(([0], np.cumsum(counts)))
+                for (o, s) in b:
+                    d = int(np.searchsorted(starts, o - off, side="right") - 1)
+                    while counts[d] == 0 or starts[d] != o - off:
+                        d += 1
+                    nxt.append((o, s, by_digit[starts[d]:starts[d] + s]))
+                    out_b.add((o, s))
+        level_buckets = nxt
+    return out_b, out_t

@@ -2,6 +2,8 @@
 include/gpusort.h declares; host-side sizing logic; no compute calls."""
 import ctypes as C
 import os
+
+import pytest
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

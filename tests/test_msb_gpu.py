@@ -157,6 +157,26 @@ def test_large_properties(gs, cuda, dist):
     assert bad == 0 and vsum == n * (n - 1) // 2
 
 
+def test_config4_zipf_2p30_through_rdxsrt_unstable_sort(gs, cuda):
+    """BASELINE configs[3] at full size: 2^30 Zipf keys through the MSB path (keys only, so the heavy-hitter path is
+    on): sorted, same multiset, result in the caller's input array, and the census shows the heavy hitters being taken
+    out at level 2 instead of travelling to the last byte."""
+    from gpu_sort_amd.msb import msb_census
+    n = 1 << 30
+    keys = gs.generate_zipf_keys(n, seed=0, device=cuda)
+    _, s0, x0 = gs.check_sorted(keys)
+    alt = torch.empty_like(keys)
+    dm = torch.empty(gs.lib.gs_msb_temp_bytes(n, 0), dtype=torch.uint8, device=cuda)
+    seq = gs.rdxsrt_unstable_sort(keys, None, n, alt, None, pre_allocated_dm=dm)
+    assert seq.sorted_keys.data_ptr() == keys.data_ptr()
+    inv, s1, x1 = gs.check_sorted(seq.sorted_keys)
+    assert inv == 0 and (s1, x1) == (s0, x0)
+    cen = msb_census(dm, n)
+    assert cen[0]["keys"] == n and cen[1]["keys"] == n            # every top-byte bucket is far above the local-sort capacity
+    assert cen[2]["pivot_keys"] > 0.45 * n                         # the ~4000 heavy values: half of the keys
+    assert cen[3]["keys"] < 0.15 * n                               # (51 % without the heavy-hitter path)
+
+
 @pytest.mark.parametrize("n", [1500, 4000, 9000, 17000, 17408, 40000, 700001])
 def test_all_ones_keys_next_to_padding(gs, cuda, oracle, n):
     """Keys whose low bits are all ones tie with the local sort's padding value in every digit:
