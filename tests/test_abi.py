@@ -110,3 +110,44 @@ def test_shim_reports_failures_instead_of_returning_unsorted_data():
     out = subprocess.run([exe, "nodevice"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
     assert out.stderr.count("gpusort: rdxsrt_unstable_sort") == 3
+
+
+def test_rccl_host_library_exports_and_split_rule(gs):
+    """libgpusort_rccl.so (the C++ host of the bucket-sharded sort, include/gpusort_rccl.h) loads here, exports what its
+    header declares, and its bucket -> rank rule agrees with the Python host's (gpu-sort_amd/sharded.py::compute_splits)
+    on random and on lopsided bucket sizes -- both sides of an exchange must cut at the same places."""
+    import numpy as np
+    from gpu_sort_amd import sharded
+    path = os.path.join(ROOT, "gpu-sort_amd", "lib", "libgpusort_rccl.so")
+    if not os.path.exists(path):
+        pytest.skip("libgpusort_rccl.so not built (run __graft_entry__.build())")
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "gpusort_rccl.h")).read(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", text)))
+    assert syms == ["gs_msb_sharded_temp_bytes", "gs_msb_sort_u32_sharded", "gs_sharded_compute_splits"]
+    lib = C.CDLL(path)
+    for name in syms:
+        assert hasattr(lib, name)
+    lib.gs_msb_sharded_temp_bytes.restype = C.c_size_t
+    lib.gs_msb_sharded_temp_bytes.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int]
+    assert lib.gs_msb_sharded_temp_bytes(1 << 30, (1 << 30) + (1 << 28), 0, 8) >= gs.lib.gs_msb_finish_temp_bytes((1 << 30) + (1 << 28), 0, 8)
+    lib.gs_sharded_compute_splits.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    for world in (1, 2, 3, 8):
+        for kind in ("uniform", "lopsided", "empty", "one_bucket"):
+            h = rng.integers(0, 1 << 22, size=(world, 256)).astype(np.uint64)
+            if kind == "lopsided":
+                h[:, 17] *= 300
+            if kind == "empty":
+                h[:] = 0
+            if kind == "one_bucket":
+                h[:] = 0
+                h[:, 200] = 12345
+            dest = np.zeros(256, np.uint8)
+            per = np.zeros(world, np.uint64)
+            lib.gs_sharded_compute_splits(h.ctypes.data_as(C.c_void_p), world, dest.ctypes.data_as(C.c_void_p), per.ctypes.data_as(C.c_void_p))
+            ed, ep = sharded.compute_splits(h, world)
+            assert np.array_equal(dest, ed) and np.array_equal(per.astype(np.int64), ep), (world, kind)
+    # argument validation happens before any GPU or RCCL call
+    lib.gs_msb_sort_u32_sharded.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 2 + [C.c_uint64] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    n_out = C.c_uint64(0)
+    assert lib.gs_msb_sort_u32_sharded(None, 0, None, None, 10, None, None, None, None, None, None, 10, C.byref(n_out), None, 0, 1, 0, None) == 1

@@ -73,3 +73,13 @@ def test_shim_too_small_data_manager_yields_null():
     """A pre-allocated RDXSRT_GPUDataManager sized for fewer keys: {nullptr, nullptr}, not the unsorted input."""
     out = _run(["shim_errors", "gpu"])
     assert out[-1] == "OK"
+
+
+def test_cpp_sharded_host_on_a_one_rank_rccl_communicator():
+    """gs_msb_sort_u32_sharded (C++ host, RCCL called directly: first pass -> ncclAllGather of the bucket sizes ->
+    one grouped ncclSend/ncclRecv exchange -> finish) on the one GPU of the box: a one-rank communicator, keys and pairs,
+    every rank's slice verified (sorted, global multiset unchanged)."""
+    for extra in ([], ["--pairs"]):
+        out = _run(["msb_sharded", "--log2n", "24", "--reps", "2"] + extra)
+        rec = json.loads(out[-1])
+        assert rec["verified"] is True and rec["n_gpus"] == 1 and rec["rank0_received"] == 1 << 24

@@ -1,4 +1,5 @@
-timeout -k 10 900 python -m pytest tests/test_msb_gpu.py -x -q -k "config4 or large" 2>&1 | tail -3
-python bench.py --algo msb --dist zipf --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null
-python bench.py --algo msb --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null
-python bench.py --dist zipf --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null
+cd gpu-sort_amd/drivers
+timeout -k 10 120 ./msb_sharded --log2n 24 --reps 2; echo rc=$?
+timeout -k 10 120 ./msb_sharded --log2n 24 --reps 2 --pairs; echo rc=$?
+timeout -k 10 200 ./msb_sharded --log2n 30 --reps 3; echo rc=$?
+cd ../.. && timeout -k 10 600 python -m pytest tests/test_drivers_gpu.py -x -q 2>&1 | tail -3
