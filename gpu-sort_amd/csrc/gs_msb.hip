@@ -658,7 +658,7 @@ __device__ __forceinline__ void msb_scatter_tile(ScatterSmem<HAS_VALUES, REMAP> 
     if (!HAS_VALUES) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int i = 0; i < MSB_KPT; ++i) {
-        const uint32_t slot = (uint32_t)tid + i * MSB_THREADS;
+        const uint32_t slot = (uint32_t)w * (WAVE * MSB_KPT) + i * WAVE + lane;   // wave-contiguous (see lsb_downsweep_kernel)
         uint32_t k, v = 0;
         if (HAS_VALUES) {
             const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[slot];

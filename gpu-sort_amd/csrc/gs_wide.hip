@@ -195,7 +195,7 @@ __global__ __launch_bounds__(W_THREADS, 4) void wide_downsweep_kernel(const K *_
     uint32_t dst[W_KPT];
 #pragma unroll
     for (int i = 0; i < W_KPT; ++i) {
-        const uint32_t slot = (uint32_t)tid + i * W_THREADS;
+        const uint32_t slot = (uint32_t)w * (WAVE * W_KPT) + i * WAVE + lane;   // wave-contiguous (see lsb_downsweep_kernel)
         const K k = stage_k[slot];
         dst[i] = gbase[w_digit(k, p)] + slot;
         if (slot < valid) keys_out[dst[i]] = w_twiddle_out<K>(k, p.f_out, p.xor_out);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(W_THREADS, 4) void wide_downsweep_kernel(const K *_
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < W_KPT; ++i) {
-            const uint32_t slot = (uint32_t)tid + i * W_THREADS;
+            const uint32_t slot = (uint32_t)w * (WAVE * W_KPT) + i * WAVE + lane;
             if (slot < valid) vals_out[dst[i]] = stage_v[slot];
         }
     }

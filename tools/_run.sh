@@ -1,5 +1,7 @@
-cd gpu-sort_amd/drivers
-timeout -k 10 120 ./msb_sharded --log2n 24 --reps 2; echo rc=$?
-timeout -k 10 120 ./msb_sharded --log2n 24 --reps 2 --pairs; echo rc=$?
-timeout -k 10 200 ./msb_sharded --log2n 30 --reps 3; echo rc=$?
-cd ../.. && timeout -k 10 600 python -m pytest tests/test_drivers_gpu.py -x -q 2>&1 | tail -3
+python tools/kprof.py 30 2>&1 | grep -E "sum"
+python tools/kprof.py 30 pairs 2>&1 | grep -E "sum"
+python tools/kprof.py 30 keys msb 2>&1 | grep -E "sum|partition"
+python tools/kprof.py 30 pairs msb 2>&1 | grep -E "sum|partition"
+python tools/kprof.py 30 keys msb zipf 2>&1 | grep -E "sum"
+python tools/wide_bench.py 2>&1 | grep -v amdgpu | tail -5
+timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
