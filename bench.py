@@ -78,9 +78,9 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def load_pmc_traffic():
+def load_pmc_traffic(pairs=False):
     """HBM bytes per downsweep launch from the committed rocprofv3 --pmc summary, or None."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_pairs.json" if pairs else "pmc_traffic.json")
     try:
         with open(path) as f:
             return json.load(f)
@@ -321,7 +321,7 @@ def main():
             # keys per launch: the whole array on one GPU; a rank's received slice (~n) when sharded
             alg_bytes = DOWNSWEEP_BYTES_PER_KEY[args.pairs] * n
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-            pmc = load_pmc_traffic()
+            pmc = load_pmc_traffic(args.pairs)
             traffic = None
             if pmc and pmc.get("kernel") == dom and pmc.get("log2n") == args.log2n and bool(pmc.get("pairs")) == args.pairs:
                 traffic = pmc.get("hbm_bytes_per_launch")
