@@ -1,1 +1,5 @@
-for L in libgpusort.so libgpusort_splitvals.so libgpusort.so libgpusort_splitvals.so; do echo == $L; GS_LIB_PATH=$PWD/gpu-sort_amd/lib/$L python tools/kprof.py 30 pairs 2>&1 | grep -E "downsweep|sum"; done
+python tools/kprof.py 30 keys msb zipf 2>&1 | grep -E "sum|histogram|upsweep"
+python tools/kprof.py 30 keys msb uniform 2>&1 | grep -E "sum|histogram|upsweep"
+python tools/kprof.py 30 keys lsb zipf 2>&1 | grep -E "sum|upsweep"
+python tools/kprof.py 30 keys lsb uniform 2>&1 | grep -E "sum|upsweep"
+python tools/dist_bench.py 28 2>&1 | grep -v amdgpu.ids
