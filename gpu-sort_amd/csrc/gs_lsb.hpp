@@ -77,6 +77,9 @@ int lsb_scan(uint32_t *spine, uint32_t *totals, uint32_t grid, hipStream_t s);
 int lsb_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, const uint32_t *spine,
                   const uint16_t *prefix16, const uint32_t *totals, const PassParams &p, hipStream_t s);
 
+// gs_wide.hip: digit totals of the last wide pass inside its workspace
+const uint32_t *wide_totals_ptr(void *d_temp, uint64_t n);
+
 // single-workgroup stable sort of a small array (gs_msb.hip): n <= small_sort_capacity(pairs)
 uint32_t small_sort_capacity(bool pairs);
 int small_stable_sort(void *scratch, size_t scratch_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,

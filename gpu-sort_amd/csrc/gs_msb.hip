@@ -108,46 +108,62 @@ struct MsbWs {
     // every reader of a device-side count is bounded by them, so that a wrong count (a bug) gives a wrong result a
     // test can catch instead of an out-of-bounds access (a GPU memory fault can take the whole node down)
     uint32_t max_buckets, max_tasks, max_tiles, stride;
+    // geometry of the kernels that work on this workspace: the u32 kernels of this file (tiles of 8192 keys, 32-bit keys,
+    // local-sort classes of 2048 / 4608 / 9216 / 17408) or the wide ones further down (64-bit keys and / or values: tiles
+    // of 4096 elements, classes of 2048 / 8192); expand, scan and classify serve both through these fields
+    uint32_t tile_shift, key_bits, caps[MSB_NCLASS];
 };
+constexpr int MSB_LEVELS = 10;           // level records: a 64-bit key has 8 byte levels (+ one the classification may write past the last)
+__host__ __device__ inline uint32_t ws_tiles_of(const MsbWs &ws, uint32_t x)
+{
+    return (x >> ws.tile_shift) + ((x & ((1u << ws.tile_shift) - 1u)) ? 1u : 0u);
+}
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // `extra`: pieces of the multi-GPU finish (each may add a ragged tile), 0 otherwise
-static inline uint32_t msb_max_buckets(uint64_t n, bool has_values, uint32_t extra = 0)
+static inline uint32_t msb_max_buckets(uint64_t n, bool has_values, uint32_t extra = 0, uint32_t cap_max = 0)
 {
-    return (uint32_t)(n / msb_class_cap(msb_num_classes(has_values) - 1)) + RADIX + 1 + extra;
+    return (uint32_t)(n / (cap_max ? cap_max : msb_class_cap(msb_num_classes(has_values) - 1))) + RADIX + 1 + extra;
 }
 // `extra_tasks`: segments of a segmented sort (each may be one task)
-static inline uint32_t msb_max_tasks(uint64_t n, bool has_values, uint32_t extra = 0, uint32_t extra_tasks = 0)
+static inline uint32_t msb_max_tasks(uint64_t n, bool has_values, uint32_t extra = 0, uint32_t extra_tasks = 0, uint32_t cap_max = 0)
 {
     // a task is either >= MSB_MERGE keys or is followed by something that did not fit: <= 2n/MERGE,
     // plus up to 256 per partitioned bucket
     // (+ two stranger ranges per heavy-hitter bucket)
-    return (uint32_t)(2 * n / MSB_MERGE) + 3 * msb_max_buckets(n, has_values, extra) + 2 * RADIX + extra_tasks;
+    return (uint32_t)(2 * n / MSB_MERGE) + 3 * msb_max_buckets(n, has_values, extra, cap_max) + 2 * RADIX + extra_tasks;
 }
 // tiles of a level: n / TILE full ones + one ragged tile per bucket, padded to whole chunks + one spare chunk
-static inline uint32_t msb_max_tiles(uint64_t n, bool has_values, uint32_t extra = 0)
+static inline uint32_t msb_max_tiles(uint64_t n, bool has_values, uint32_t extra = 0, uint32_t cap_max = 0, uint32_t tile = MSB_TILE)
 {
-    const uint64_t t = n / MSB_TILE + msb_max_buckets(n, has_values, extra) + 1;
+    const uint64_t t = n / tile + msb_max_buckets(n, has_values, extra, cap_max) + 1;
     return (uint32_t)((t / MSB_WAVES + 2) * MSB_WAVES);
 }
-static size_t msb_ws_bytes(uint64_t n, bool has_values, uint32_t extra = 0, uint32_t extra_tasks = 0)
+// `wide_cap` != 0: the geometry of the wide kernels (tiles of 4096 elements, largest local sort of `wide_cap` elements)
+static size_t msb_ws_bytes(uint64_t n, bool has_values, uint32_t extra = 0, uint32_t extra_tasks = 0, uint32_t wide_cap = 0)
 {
-    const size_t mb = msb_max_buckets(n, has_values, extra), mt = msb_max_tasks(n, has_values, extra, extra_tasks),
-                 ml = msb_max_tiles(n, has_values, extra);
-    return align256(5 * sizeof(MsbLevel)) + 2 * align256(mb * sizeof(MsbBucket)) + align256(ml * sizeof(MsbTile)) +
+    const uint32_t tile = wide_cap ? 4096u : (uint32_t)MSB_TILE;
+    const size_t mb = msb_max_buckets(n, has_values, extra, wide_cap), mt = msb_max_tasks(n, has_values, extra, extra_tasks, wide_cap),
+                 ml = msb_max_tiles(n, has_values, extra, wide_cap, tile);
+    return align256(MSB_LEVELS * sizeof(MsbLevel)) + 2 * align256(mb * sizeof(MsbBucket)) + align256(ml * sizeof(MsbTile)) +
            align256(mb * RADIX * sizeof(uint32_t)) + align256((size_t)RADIX * (ml / MSB_WAVES) * sizeof(uint32_t)) +
            align256(ml * RADIX * sizeof(uint16_t)) + MSB_NCLASS * align256(mt * sizeof(MsbTask)) +
            align256((size_t)extra * sizeof(MsbPiece)) + align256(mb * sizeof(MsbPivot));
 }
-static MsbWs msb_carve(void *temp, uint64_t n, bool has_values, uint32_t extra = 0, uint32_t extra_tasks = 0)
+static MsbWs msb_carve(void *temp, uint64_t n, bool has_values, uint32_t extra = 0, uint32_t extra_tasks = 0, uint32_t wide_cap = 0,
+                       uint32_t key_bits = 32)
 {
     MsbWs ws;
-    ws.max_buckets = msb_max_buckets(n, has_values, extra);
-    ws.max_tasks = msb_max_tasks(n, has_values, extra, extra_tasks);
-    ws.max_tiles = msb_max_tiles(n, has_values, extra);
+    const uint32_t tile = wide_cap ? 4096u : (uint32_t)MSB_TILE;
+    ws.max_buckets = msb_max_buckets(n, has_values, extra, wide_cap);
+    ws.max_tasks = msb_max_tasks(n, has_values, extra, extra_tasks, wide_cap);
+    ws.max_tiles = msb_max_tiles(n, has_values, extra, wide_cap, tile);
     ws.stride = ws.max_tiles / MSB_WAVES;
+    ws.tile_shift = wide_cap ? 12u : 13u;
+    ws.key_bits = key_bits;
+    for (int q = 0; q < MSB_NCLASS; ++q) ws.caps[q] = wide_cap ? (q == 0 ? 2048u : wide_cap) : msb_class_cap(q);
     char *c = (char *)temp;
-    ws.level = (MsbLevel *)c; c += align256(5 * sizeof(MsbLevel));
+    ws.level = (MsbLevel *)c; c += align256(MSB_LEVELS * sizeof(MsbLevel));
     for (int i = 0; i < 2; ++i) { ws.buckets[i] = (MsbBucket *)c; c += align256((size_t)ws.max_buckets * sizeof(MsbBucket)); }
     ws.tiles = (MsbTile *)c; c += align256((size_t)ws.max_tiles * sizeof(MsbTile));
     ws.cursors = (uint32_t *)c; c += align256((size_t)ws.max_buckets * RADIX * sizeof(uint32_t));
@@ -163,12 +179,12 @@ static MsbWs msb_carve(void *temp, uint64_t n, bool has_values, uint32_t extra =
 __global__ void msb_init_kernel(MsbWs ws, uint32_t n)
 {
     const int t = threadIdx.x;
-    if (t < 5) {
+    if (t < MSB_LEVELS) {
         MsbLevel z{};
-        if (t == 0) { z.packed = (1ull << 32) | msb_tiles_of(n); z.keys = n; }
+        if (t == 0) { z.packed = (1ull << 32) | ws_tiles_of(ws, n); z.keys = n; }
         ws.level[t] = z;
     }
-    if (t == 0) ws.buckets[0][0] = MsbBucket{0u, n, 0u, msb_tiles_of(n)};
+    if (t == 0) ws.buckets[0][0] = MsbBucket{0u, n, 0u, ws_tiles_of(ws, n)};
 }
 
 // direct path for arrays that fit one workgroup: a single task on all 32 bits
@@ -201,9 +217,10 @@ __global__ __launch_bounds__(256) void msb_expand_kernel(MsbWs ws, int L, const 
             if (lane == 0) ws.pivots[b] = MsbPivot{cand, 0u, 0u, 0u, 0u, 0u, hits >= 3u ? 1u : 0u, 0u};
         }
         for (uint32_t t = threadIdx.x; t < B.tiles; t += blockDim.x) {
-            const uint32_t lo = B.offset + t * MSB_TILE, left = B.size - t * MSB_TILE;
+            const uint32_t tl = 1u << ws.tile_shift;
+            const uint32_t lo = B.offset + t * tl, left = B.size - t * tl;
             if (B.tile_start + t < ws.max_tiles)
-                ws.tiles[B.tile_start + t] = MsbTile{lo, left < (uint32_t)MSB_TILE ? left : (uint32_t)MSB_TILE, b, 0u};
+                ws.tiles[B.tile_start + t] = MsbTile{lo, left < tl ? left : tl, b, 0u};
         }
     }
 }
@@ -386,8 +403,8 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
     uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
     if (nb > ws.max_buckets) nb = ws.max_buckets;              // never (see MsbWs)
     const int d = threadIdx.x;
-    const uint32_t cap_max = msb_class_cap(nclass - 1);
-    const uint32_t rb = 24u - 8u * (uint32_t)L;                  // bits below this level's byte
+    const uint32_t cap_max = nclass > 0 ? ws.caps[nclass - 1] : 0xffffffffu;   // nclass 0: cursors only (LAST)
+    const uint32_t rb = ws.key_bits - 8u - 8u * (uint32_t)L;     // bits below this level's byte
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const MsbBucket B = ws.buckets[L & 1][b];
         if (PIVOT) {
@@ -404,7 +421,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
                     for (int q = 0; q < 2; ++q) {
                         if (sizes[q] == 0) continue;
                         int cls = 0;
-                        while (msb_class_cap(cls) < sizes[q]) ++cls;
+                        while (ws.caps[cls] < sizes[q]) ++cls;
                         const uint32_t at = atomicAdd(&ws.level[L].task_count[cls], 1u);
                         if (at < ws.max_tasks) ws.tasks[cls][at] = MsbTask{offs[q], sizes[q], rb + 8u, 0u};
                     }
@@ -456,8 +473,8 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
         const bool is_large = s_large[d] != 0;
         const uint32_t tsize = s_task[d];
         int cls = 0;
-        if (tsize) while (msb_class_cap(cls) < tsize) ++cls;
-        const uint32_t tiles = is_large ? msb_tiles_of(c) : 0u;
+        if (tsize) while (ws.caps[cls] < tsize) ++cls;
+        const uint32_t tiles = is_large ? ws_tiles_of(ws, c) : 0u;
         // exclusive prefixes inside the block (bucket index, tile index) keep tile_start sorted
         const uint32_t bidx = block_exclusive_scan_256(is_large ? 1u : 0u, scratch, &s_tot[0]);
         const uint32_t tidx = block_exclusive_scan_256(tiles, scratch, &s_tot[1]);
@@ -1442,6 +1459,343 @@ int small_stable_sort(void *scratch, size_t scratch_bytes, const uint32_t *kin, 
     return (int)hipGetLastError();
 }
 
+
+// ================================================================ wide MSB ==
+// rdxsrt_unstable_sort for 64-bit keys and / or 64-bit values: the reference instantiates its hybrid sort for 8-byte keys
+// and values too (RadixSortConfig<8,*>, msb/src/sort/gpu_sort_config.h:179-198; msb/tests/test_sort_keys.cu:154-195,
+// test_sort_pairs.cu:223-281).  Same structure as the 32-bit path above -- top byte with one stable pass (the wide LSB
+// pass of gs_wide.hip), then per level: expand / upsweep / scan / classify / scatter on the bucket lists, buckets that fit a
+// workgroup finished by an LSD local sort in LDS on their remaining bits -- with kernels of their own for the element
+// types: tiles of 4096 elements (8 per thread), keys and values staged one after the other through one LDS buffer, local
+// sorts of up to 2048 / 8192 elements.  expand, scan and classify are the kernels above (geometry from MsbWs).  Keys stay in
+// the caller's representation in memory; the order-preserving transform is applied where a digit is taken.
+constexpr int MW_THREADS = 512, MW_WAVES = MW_THREADS / WAVE, MW_KPT = 8, MW_TILE = MW_THREADS * MW_KPT;
+constexpr uint32_t MW_CAP = 8192;                 // largest local sort (elements)
+struct MwNoVal {};
+
+template <typename K> __device__ __forceinline__ K mw_tw_in(K k, int f, uint64_t x)
+{
+    if constexpr (sizeof(K) == 8) { if (f) k ^= (uint64_t)((int64_t)k >> 63) | 0x8000000000000000ull; return k ^ x; }
+    else return twiddle_in((uint32_t)k, f, (uint32_t)x);
+}
+template <typename K> __device__ __forceinline__ K mw_tw_out(K k, int f, uint64_t x)
+{
+    if constexpr (sizeof(K) == 8) { k ^= x; if (f) k ^= ~(uint64_t)((int64_t)k >> 63) | 0x8000000000000000ull; return k; }
+    else return twiddle_out((uint32_t)k, f, (uint32_t)x);
+}
+
+template <typename K>
+__global__ __launch_bounds__(MW_THREADS) void mw_upsweep_kernel(MsbWs ws, int L, const K *__restrict__ src, uint32_t shift, int f_in,
+                                                                uint64_t xor_in)
+{
+    __shared__ uint32_t lh[MW_WAVES][RADIX];
+    uint32_t ntiles = (uint32_t)ws.level[L].packed;
+    if (ntiles > ws.max_tiles - MW_WAVES) ntiles = ws.max_tiles - MW_WAVES;
+    const uint32_t nchunks = ntiles / MW_WAVES + 1;
+    const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
+    uint32_t *my = lh[w];
+    constexpr int BATCH = 16;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
+        const uint32_t g = c * MW_WAVES + (uint32_t)w;
+        if (g < ntiles) {
+            const MsbTile T = ws.tiles[g];
+            const K *p = src + T.lo;
+            const uint32_t last = T.valid - 1u;
+#pragma unroll 1
+            for (uint32_t j = 0; j < T.valid; j += BATCH * WAVE) {
+                K v[BATCH];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const uint32_t idx = j + u * WAVE + lane;
+                    v[u] = __builtin_nontemporal_load(&p[idx < last ? idx : last]);
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u)
+                    if (j + u * WAVE + lane < T.valid) hist_add(my, (uint32_t)(mw_tw_in<K>(v[u], f_in, xor_in) >> shift) & 0xffu);
+            }
+        }
+        __syncthreads();
+        if (tid < RADIX) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int j = 0; j < MW_WAVES; ++j) {
+                ws.prefix16[(size_t)(c * MW_WAVES + j) * RADIX + tid] = (uint16_t)run;
+                run += lh[j][tid];
+            }
+            ws.spine[(size_t)tid * ws.stride + c] = run;
+        }
+        __syncthreads();
+    }
+}
+
+// ranks of the wave's KPT rounds by ballot match + wave-private counters (as in the scatter above); `dig(i)` = digit of round i
+template <int KPT, typename F>
+__device__ __forceinline__ void mw_rank(uint32_t *my, uint32_t (&pos)[KPT], F dig)
+{
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const uint32_t d = dig(i);
+        uint32_t lo, hi;
+        match_digit(d, lo, hi);
+        const uint32_t lower = count_lower(lo, hi);
+        pos[i] = my[d] + lower;
+        if (lower == 0)
+            __hip_atomic_fetch_add(&my[d], (uint32_t)(__popc(lo) + __popc(hi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]));
+}
+// wave 0: the WAVES rows of wave-private counts -> element bases per (wave, digit) in place; returns nothing, writes
+// ex4 (exclusive prefix of the block's digit totals, digits 4l..4l+3 of lane l) for the caller
+template <int WAVES>
+__device__ __forceinline__ void mw_scan_rows(uint32_t (*whist)[RADIX], uint32_t (&ex)[4])
+{
+    const int lane = lane_id();
+    uint32_t run[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < WAVES; ++j) {
+        const uint4 x = reinterpret_cast<const uint4 *>(whist[j])[lane];
+        run[0] += x.x; run[1] += x.y; run[2] += x.z; run[3] += x.w;
+    }
+    const uint32_t lane_sum = run[0] + run[1] + run[2] + run[3];
+    ex[0] = wave_inclusive_scan(lane_sum) - lane_sum;
+    ex[1] = ex[0] + run[0];
+    ex[2] = ex[1] + run[1];
+    ex[3] = ex[2] + run[2];
+    uint4 e4 = make_uint4(ex[0], ex[1], ex[2], ex[3]);
+#pragma unroll
+    for (int j = 0; j < WAVES; ++j) {
+        const uint4 x = reinterpret_cast<const uint4 *>(whist[j])[lane];
+        reinterpret_cast<uint4 *>(whist[j])[lane] = e4;
+        e4.x += x.x; e4.y += x.y; e4.z += x.z; e4.w += x.w;
+    }
+}
+
+// one level tile: stable counting-sort scatter on byte `shift / 8` (ragged tiles included: pads rank last and are not stored)
+template <typename K, typename V>
+__global__ __launch_bounds__(MW_THREADS, 4) void mw_scatter_kernel(MsbWs ws, int L, const K *__restrict__ src_k, K *__restrict__ dst_k,
+                                                                   const V *__restrict__ src_v, V *__restrict__ dst_v, uint32_t shift,
+                                                                   int f_in, uint64_t xor_in)
+{
+    constexpr bool HAS_VALUES = !std::is_same<V, MwNoVal>::value;
+    constexpr size_t ELEM = sizeof(K) > (HAS_VALUES ? sizeof(V) : 1) ? sizeof(K) : sizeof(V);
+    __shared__ __attribute__((aligned(16))) uint32_t whist[MW_WAVES][RADIX];
+    __shared__ __attribute__((aligned(16))) uint32_t gbase[RADIX];
+    __shared__ __attribute__((aligned(16))) unsigned char stage_raw[MW_TILE * ELEM];
+    K *stage_k = reinterpret_cast<K *>(stage_raw);
+    const uint32_t ntiles = (uint32_t)ws.level[L].packed;
+    if (blockIdx.x >= ntiles || blockIdx.x >= ws.max_tiles) return;
+    const uint32_t g = tile_of_item(blockIdx.x, ntiles);
+    const MsbTile T = ws.tiles[g];
+    const int lane = lane_id(), w = wave_id();
+    uint32_t *my = whist[w];
+    const uint32_t wbase = (uint32_t)w * (WAVE * MW_KPT) + lane, valid = T.valid;
+    uint32_t tbase[4] = {0, 0, 0, 0};
+    if (w == 0) {
+        const uint4 cur = reinterpret_cast<const uint4 *>(ws.cursors + (size_t)T.bucket * RADIX)[lane];
+        const uint32_t *sp = ws.spine + g / MW_WAVES + (size_t)(4 * lane) * ws.stride;
+        const uint2 pf = reinterpret_cast<const uint2 *>(ws.prefix16 + (size_t)g * RADIX)[lane];
+        tbase[0] = cur.x + sp[0] + (pf.x & 0xffffu);
+        tbase[1] = cur.y + sp[ws.stride] + (pf.x >> 16);
+        tbase[2] = cur.z + sp[2 * (size_t)ws.stride] + (pf.y & 0xffffu);
+        tbase[3] = cur.w + sp[3 * (size_t)ws.stride] + (pf.y >> 16);
+    }
+    K key[MW_KPT];
+    uint32_t pos[MW_KPT];
+    const K *pk = src_k + T.lo;
+#pragma unroll
+    for (int i = 0; i < MW_KPT; ++i) {
+        const uint32_t idx = wbase + i * WAVE;
+        key[i] = pk[idx < valid ? idx : valid - 1u];
+    }
+    auto digit_of = [&](K k) { return (uint32_t)(mw_tw_in<K>(k, f_in, xor_in) >> shift) & 0xffu; };
+#pragma unroll
+    for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
+    mw_rank<MW_KPT>(my, pos, [&](int i) { return (wbase + i * WAVE < valid) ? digit_of(key[i]) : 255u; });
+    __syncthreads();
+    if (w == 0) {
+        uint32_t ex[4];
+        mw_scan_rows<MW_WAVES>(whist, ex);
+        reinterpret_cast<uint4 *>(gbase)[lane] = make_uint4(tbase[0] - ex[0], tbase[1] - ex[1], tbase[2] - ex[2], tbase[3] - ex[3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MW_KPT; ++i) {
+        pos[i] += my[(wbase + i * WAVE < valid) ? digit_of(key[i]) : 255u];
+        stage_k[pos[i]] = key[i];
+    }
+    __syncthreads();
+    uint32_t dst[MW_KPT];
+#pragma unroll
+    for (int i = 0; i < MW_KPT; ++i) {
+        const uint32_t slot = wbase + i * WAVE;          // wave-contiguous slots (see lsb_downsweep_kernel)
+        const K k = stage_k[slot];
+        dst[i] = gbase[digit_of(k)] + slot;
+        if (slot < valid) dst_k[dst[i]] = k;
+    }
+    if constexpr (HAS_VALUES) {
+        V *stage_v = reinterpret_cast<V *>(stage_raw);
+        V val[MW_KPT];
+        const V *pv = src_v + T.lo;
+#pragma unroll
+        for (int i = 0; i < MW_KPT; ++i) {
+            const uint32_t idx = wbase + i * WAVE;
+            val[i] = pv[idx < valid ? idx : valid - 1u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MW_KPT; ++i) stage_v[pos[i]] = val[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MW_KPT; ++i) {
+            const uint32_t slot = wbase + i * WAVE;
+            if (slot < valid) dst_v[dst[i]] = stage_v[slot];
+        }
+    }
+}
+
+// local sort of one class: LSD passes of 8 bits over the task's low `sort_bits` bits, all stable (ballot match), keys
+// (and values) exchanged through LDS after every pass; pads are all-ones keys, which every pass ranks last
+template <typename K, typename V, int KPT>
+__global__ __launch_bounds__(MW_THREADS, KPT > 8 ? 2 : 4) void mw_local_sort_kernel(MsbWs ws, int L, int cls, const K *__restrict__ src_k,
+                                                                                    K *__restrict__ dst_k, const V *__restrict__ src_v,
+                                                                                    V *__restrict__ dst_v, int f, uint64_t x)
+{
+    constexpr bool HAS_VALUES = !std::is_same<V, MwNoVal>::value;
+    constexpr size_t ELEM = sizeof(K) > (HAS_VALUES ? sizeof(V) : 1) ? sizeof(K) : sizeof(V);
+    constexpr int CAP = MW_THREADS * KPT;
+    __shared__ __attribute__((aligned(16))) uint32_t whist[MW_WAVES][RADIX];
+    __shared__ __attribute__((aligned(16))) unsigned char stage_raw[CAP * ELEM];
+    K *stage_k = reinterpret_cast<K *>(stage_raw);
+    V *stage_v = reinterpret_cast<V *>(stage_raw);
+    uint32_t ntasks = ws.level[L].task_count[cls];
+    if (ntasks > ws.max_tasks) ntasks = ws.max_tasks;
+    const int lane = lane_id(), w = wave_id();
+    uint32_t *my = whist[w];
+    const uint32_t wbase = (uint32_t)w * (WAVE * KPT) + lane;
+    for (uint32_t t = blockIdx.x; t < ntasks; t += gridDim.x) {
+        const MsbTask T = ws.tasks[cls][t];
+        const uint32_t size = T.size < (uint32_t)CAP ? T.size : (uint32_t)CAP, last = size - 1u;
+        K key[KPT];
+        V val[HAS_VALUES ? KPT : 1];
+        uint32_t pos[KPT];
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = wbase + i * WAVE;
+            const K k = mw_tw_in<K>(src_k[T.offset + (idx < size ? idx : last)], f, x);
+            key[i] = idx < size ? k : (K) ~(K)0;
+            if constexpr (HAS_VALUES) val[i] = src_v[T.offset + (idx < size ? idx : last)];
+        }
+#pragma unroll 1
+        for (uint32_t shift = 0; shift < T.sort_bits; shift += 8) {
+#pragma unroll
+            for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
+            mw_rank<KPT>(my, pos, [&](int i) { return (uint32_t)(key[i] >> shift) & 0xffu; });
+            __syncthreads();
+            if (w == 0) { uint32_t ex[4]; mw_scan_rows<MW_WAVES>(whist, ex); }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                pos[i] += my[(uint32_t)(key[i] >> shift) & 0xffu];
+                stage_k[pos[i]] = key[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) key[i] = stage_k[wbase + i * WAVE];
+            if constexpr (HAS_VALUES) {
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) stage_v[pos[i]] = val[i];
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) val[i] = stage_v[wbase + i * WAVE];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t idx = wbase + i * WAVE;
+            if (idx < size) {
+                dst_k[T.offset + idx] = mw_tw_out<K>(key[i], f, x);
+                if constexpr (HAS_VALUES) dst_v[T.offset + idx] = val[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void mw_single_task_kernel(MsbWs ws, uint32_t n, int cls, uint32_t bits)
+{
+    if (threadIdx.x == 0) { ws.tasks[cls][0] = MsbTask{0u, n, bits, 0u}; ws.level[0].task_count[cls] = 1; }
+}
+
+template <typename K, typename V>
+static void mw_launch_local_sorts(const MsbWs &ws, int L, const K *sk, K *dk, const V *sv, V *dv, int f, uint64_t x, hipStream_t s)
+{
+    KernelTimer kt(GS_K_MSB_LOCAL_SORT, s);
+    const uint32_t g = ws.max_tasks < MSB_MAX_GRID ? ws.max_tasks : MSB_MAX_GRID;
+    hipLaunchKernelGGL((mw_local_sort_kernel<K, V, 4>), dim3(g), dim3(MW_THREADS), 0, s, ws, L, 0, sk, dk, sv, dv, f, x);
+    hipLaunchKernelGGL((mw_local_sort_kernel<K, V, 16>), dim3(g), dim3(MW_THREADS), 0, s, ws, L, 1, sk, dk, sv, dv, f, x);
+}
+
+static size_t mw_lsb_bytes(uint64_t n, int kb, int vb) { return align256(gs_lsb_wide_temp_bytes(n, kb, vb)); }
+
+template <typename K, typename V>
+static int msb_wide_sort(void *d_temp, K *keys, V *vals, uint64_t num_items, K *keys_alt, V *vals_alt, int key_type, hipStream_t s)
+{
+    constexpr bool pairs = !std::is_same<V, MwNoVal>::value;
+    constexpr int KB = (int)sizeof(K), VB = pairs ? (int)sizeof(V) : 0, key_bits = 8 * KB, nclass = 2;
+    const uint32_t n = (uint32_t)num_items;
+    const MsbWs ws = msb_carve((char *)d_temp + mw_lsb_bytes(num_items, KB, VB), num_items, pairs, 0, 0, MW_CAP, (uint32_t)key_bits);
+    const bool is_float = key_type == GS_KEY_F32 || key_type == GS_KEY_F64;
+    const bool is_signed = key_type == GS_KEY_I32 || key_type == GS_KEY_I64;
+    const int f = is_float ? 1 : 0;
+    const uint64_t x = is_signed ? (KB == 8 ? 0x8000000000000000ull : 0x80000000ull) : 0ull;
+    { KernelTimer kt(GS_K_OTHER, s); hipLaunchKernelGGL(msb_init_kernel, dim3(1), dim3(64), 0, s, ws, n); }
+    if (n <= MW_CAP) {
+        hipLaunchKernelGGL(mw_single_task_kernel, dim3(1), dim3(64), 0, s, ws, n, n <= 2048u ? 0 : 1, (uint32_t)key_bits);
+        mw_launch_local_sorts<K, V>(ws, 0, keys, keys, vals, vals, f, x, s);
+        return (int)hipGetLastError();
+    }
+    // level 0: the top byte with one stable wide LSB pass, IN -> ALT (keys keep the caller's representation)
+    void *k2[2] = {keys, keys_alt}, *v2[2] = {(void *)vals, (void *)vals_alt};
+    int sel = 0;
+    int e = gs_lsb_sort_wide(d_temp, mw_lsb_bytes(num_items, KB, VB), k2, pairs ? v2 : nullptr, &sel, num_items, KB, VB, key_bits - 8,
+                             key_bits, 0, key_type, s);
+    if (e) return e;
+    { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
+      hipLaunchKernelGGL((msb_classify_kernel<false, false>), dim3(1), dim3(256), 0, s, ws, 0, wide_totals_ptr(d_temp, num_items), nclass); }
+    mw_launch_local_sorts<K, V>(ws, 0, keys_alt, keys, vals_alt, vals, f, x, s);
+    K *buf_k[2] = {keys, keys_alt};
+    V *buf_v[2] = {vals, vals_alt};
+    const uint32_t tiles_all = (uint32_t)((num_items + MW_TILE - 1) / MW_TILE);
+    for (int L = 1; L < KB; ++L) {
+        const uint32_t shift = (uint32_t)(key_bits - 8 - 8 * L);
+        const K *sk = buf_k[L & 1];
+        K *dk = buf_k[(L + 1) & 1];
+        const V *sv = buf_v[L & 1];
+        V *dv = buf_v[(L + 1) & 1];
+        const bool last = L == KB - 1;
+        const uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
+        const uint32_t max_tiles = tiles_all + max_b;
+        { KernelTimer kt(GS_K_MSB_HISTOGRAM, s);
+          hipLaunchKernelGGL(msb_expand_kernel, dim3(max_b < 4096u ? max_b : 4096u), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr);
+          const uint32_t hg_ub = max_tiles / MW_WAVES + 1;
+          hipLaunchKernelGGL((mw_upsweep_kernel<K>), dim3(hg_ub < MSB_MAX_GRID ? hg_ub : MSB_MAX_GRID), dim3(MW_THREADS), 0, s, ws, L, sk,
+                             shift, f, x);
+          hipLaunchKernelGGL(msb_scan_kernel, dim3(RADIX), dim3(1024), 0, s, ws, L); }
+        { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
+          const uint32_t cg = max_b < 4096u ? max_b : 4096u;
+          if (last) hipLaunchKernelGGL((msb_classify_kernel<true, false>), dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass);
+          else hipLaunchKernelGGL((msb_classify_kernel<false, false>), dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass); }
+        { KernelTimer kt(GS_K_MSB_PARTITION, s);
+          hipLaunchKernelGGL((mw_scatter_kernel<K, V>), dim3(max_tiles), dim3(MW_THREADS), 0, s, ws, L, sk, dk, sv, dv, shift, f, x); }
+        if (!last) mw_launch_local_sorts<K, V>(ws, L, (const K *)dk, buf_k[0], (const V *)dv, buf_v[0], f, x, s);
+    }
+    return (int)hipGetLastError();
+}
+
 }  // namespace gs
 
 using namespace gs;
@@ -1782,7 +2136,7 @@ int gs_segmented_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], 
     lsb_twiddle_masks(key_type, descending, true, true, tw);
 
     static_assert(sizeof(MsbLevel) % 8 == 0, "levels are zeroed 8 bytes at a time");
-    hipError_t e = zero_async(ws.level, 5 * sizeof(MsbLevel), s);
+    hipError_t e = zero_async(ws.level, MSB_LEVELS * sizeof(MsbLevel), s);
     if (e != hipSuccess) return (int)e;
     { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
       const uint32_t g = (num_segments + 255u) / 256u;
@@ -1889,6 +2243,45 @@ int gs_shard_partition_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_ke
     if (pairs) launch_scatter<true, true, false>(ws, 0, grid, 1, big, d_keys_in, d_keys_out, d_vals_in, d_vals_out, dsel, 0, 0u, s);
     else launch_scatter<false, true, false>(ws, 0, grid, 1, big, d_keys_in, d_keys_out, nullptr, nullptr, dsel, 0, 0u, s);
     return (int)hipGetLastError();
+}
+
+
+size_t gs_msb_wide_temp_bytes(uint64_t num_items, int key_bytes, int val_bytes)
+{
+    return mw_lsb_bytes(num_items, key_bytes, val_bytes) + msb_ws_bytes(num_items, val_bytes != 0, 0, 0, MW_CAP);
+}
+
+int gs_msb_sort_wide(void *d_temp, size_t temp_bytes, void *d_keys, void *d_vals, uint64_t num_items, void *d_keys_alt,
+                     void *d_vals_alt, int key_bytes, int val_bytes, void **d_sorted_keys, void **d_sorted_vals, int key_type,
+                     void *stream, int synchronize)
+{
+    GS_CLEAR_STALE_ERROR();
+    if (key_bytes != 4 && key_bytes != 8) return hipErrorInvalidValue;
+    if (val_bytes != 0 && val_bytes != 4 && val_bytes != 8) return hipErrorInvalidValue;
+    if (key_bytes == 4 && val_bytes != 8) return hipErrorInvalidValue;          // (u32, none | u32) is gs_msb_sort_u32's
+    if (num_items >= (1ull << 32)) return hipErrorInvalidValue;
+    const bool k64 = key_bytes == 8;
+    if (k64 ? (key_type < GS_KEY_U64 || key_type > GS_KEY_F64) : (key_type < GS_KEY_U32 || key_type > GS_KEY_F32)) return hipErrorInvalidValue;
+    if (d_sorted_keys) *d_sorted_keys = d_keys;         // an even number of byte levels: the result is in the input arrays
+    if (d_sorted_vals) *d_sorted_vals = d_vals;
+    if (num_items == 0) return hipSuccess;
+    if ((val_bytes != 0) != (d_vals != nullptr)) return hipErrorInvalidValue;
+    if (!d_keys || !d_keys_alt || (d_vals && !d_vals_alt)) return hipErrorInvalidValue;
+    if (!d_temp || temp_bytes < gs_msb_wide_temp_bytes(num_items, key_bytes, val_bytes)) return hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    int e;
+#define GS_MW(K, V) e = msb_wide_sort<K, V>(d_temp, (K *)d_keys, (V *)d_vals, num_items, (K *)d_keys_alt, (V *)d_vals_alt, key_type, s)
+    if (k64) {
+        if (val_bytes == 0) GS_MW(uint64_t, MwNoVal);
+        else if (val_bytes == 4) GS_MW(uint64_t, uint32_t);
+        else GS_MW(uint64_t, uint64_t);
+    } else {
+        GS_MW(uint32_t, uint64_t);
+    }
+#undef GS_MW
+    if (e) return e;
+    if (synchronize) e = (int)hipStreamSynchronize(s);
+    return e;
 }
 
 }  // extern "C"

@@ -277,6 +277,10 @@ static int wide_sort(void *d_temp, void *d_keys[2], void *d_vals[2], int *select
     return hipSuccess;
 }
 
+// where a wide pass leaves its digit totals inside the workspace (the MSB path for wide types reads them after its
+// top-byte partition, which is one wide pass)
+const uint32_t *wide_totals_ptr(void *d_temp, uint64_t n) { return (const uint32_t *)((char *)d_temp + w_spine_bytes(n)); }
+
 }  // namespace gs
 
 using namespace gs;

@@ -121,3 +121,22 @@ def msb_classify_upto(dev_keys, dev_keys_alt, key_count, stop_level, pivot=True,
     buckets = {(int(hb[2 * i]), int(hb[2 * i + 1])) for i in range(nb.value)}
     tasks = {c: {(int(ht[c][3 * i]), int(ht[c][3 * i + 1]), int(ht[c][3 * i + 2])) for i in range(nt[c])} for c in range(4)}
     return buckets, tasks, dm
+
+
+def rdxsrt_unstable_sort_wide(dev_keys, dev_values, key_count, dev_sorted_keys_out, dev_sorted_values_out, key_type=None,
+                              dm=None, stream=None):
+    """The wide element types of rdxsrt_unstable_sort (gs_msb_sort_wide): int64 / float64 / uint64-as-int64 key tensors with no,
+    int32 or int64 values, and int32 keys with int64 values.  Ascending, unstable; the result is in the input tensors."""
+    kb = dev_keys.element_size()
+    vb = dev_values.element_size() if dev_values is not None else 0
+    if key_type is None:
+        key_type = {torch.int64: _lib.GS_KEY_I64, torch.float64: _lib.GS_KEY_F64, torch.int32: _lib.GS_KEY_I32,
+                    torch.float32: _lib.GS_KEY_F32}[dev_keys.dtype]
+    need = lib.gs_msb_wide_temp_bytes(key_count, kb, vb)
+    if dm is None:
+        dm = torch.empty(max(need, 1), dtype=torch.uint8, device=dev_keys.device)
+    sk, sv = C.c_void_p(), C.c_void_p()
+    check(lib.gs_msb_sort_wide(dm.data_ptr(), dm.numel(), dev_keys.data_ptr(), dev_values.data_ptr() if vb else None, key_count,
+                               dev_sorted_keys_out.data_ptr(), dev_sorted_values_out.data_ptr() if vb else None, kb, vb,
+                               C.byref(sk), C.byref(sv), key_type, _stream_ptr(stream), 1), "gs_msb_sort_wide")
+    return RDXSRT_SortedSequence(dev_keys, dev_values), dm

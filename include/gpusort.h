@@ -148,6 +148,16 @@ int gs_msb_sort_u32(void *d_temp, size_t temp_bytes,
                     uint32_t **d_sorted_keys, uint32_t **d_sorted_vals,
                     int key_type, void *stream, int synchronize);
 
+/* The same sort for the wider element types the reference instantiates (RadixSortConfig<8,*>,
+ * msb/src/sort/gpu_sort_config.h:179-198; msb/tests/test_sort_keys.cu:154-195, test_sort_pairs.cu:223-281): 64-bit keys
+ * (GS_KEY_U64 / I64 / F64) with no, 32-bit or 64-bit values, and 32-bit keys with 64-bit values.  MSD hybrid like
+ * gs_msb_sort_u32 (top byte by one stable pass, then byte levels on bucket lists, buckets of <= 8192 elements finished
+ * by an LSD local sort in LDS); ascending, unstable; the result is in the caller's input arrays.                        */
+size_t gs_msb_wide_temp_bytes(uint64_t num_items, int key_bytes, int val_bytes);
+int gs_msb_sort_wide(void *d_temp, size_t temp_bytes, void *d_keys, void *d_vals, uint64_t num_items,
+                     void *d_keys_alt, void *d_vals_alt, int key_bytes, int val_bytes,
+                     void **d_sorted_keys, void **d_sorted_vals, int key_type, void *stream, int synchronize);
+
 /* Census of the last gs_msb_sort_u32 that used d_temp (read back after synchronising `stream`): what every level
  * partitioned and what it handed to local sorts.  SURVEY.md 8d: the MSB path's algorithmic bytes are data-dependent --
  * "the harness must log the per-pass census and compute bytes from it": level 0 moves every key once (12 B/key), a level

@@ -294,27 +294,25 @@ RDXSRT_SortedSequence<KeyT, ValueT> rdxsrt_unstable_sort(KeyT *dev_keys, ValueT 
     static_assert(sizeof(KeyT) == 4 || sizeof(KeyT) == 8, "32- or 64-bit keys");
     static_assert(VB == 0 || VB == 4 || VB == 8, "32- or 64-bit values");
     if constexpr (sizeof(KeyT) == 8 || VB == 8) {
-        // 64-bit keys and/or values: the wide LSB sort; the result buffer follows from its pass count
+        // 64-bit keys and/or values: the wide kernel set of the hybrid MSB sort (gs_msb_sort_wide); result in the input arrays
         const int vb = pairs ? VB : 0;
-        const size_t tb = gs_lsb_wide_temp_bytes((uint64_t)key_count, (int)sizeof(KeyT), vb);
+        const size_t tb = gs_msb_wide_temp_bytes((uint64_t)key_count, (int)sizeof(KeyT), vb);
         void *temp = nullptr;
-        void *k2[2] = {dev_keys, dev_sorted_keys_out}, *v2[2] = {dev_values, dev_sorted_values_out};
-        int sel = 0;
         int err = (int)hipMalloc(&temp, tb ? tb : 1);
         if (err != 0) {
             gpusort::report_failure("rdxsrt_unstable_sort: scratch allocation", err);
             return RDXSRT_SortedSequence<KeyT, ValueT>{nullptr, nullptr};
         }
-        err = gs_lsb_sort_wide(temp, tb, k2, pairs ? v2 : nullptr, &sel, (uint64_t)key_count, (int)sizeof(KeyT), vb, 0,
-                               8 * (int)sizeof(KeyT), 0, gpusort::KeyTraits<KeyT>::type, stream);
-        if (err == 0) err = (int)hipStreamSynchronize(stream);
+        void *sk = nullptr, *sv = nullptr;
+        err = gs_msb_sort_wide(temp, tb, dev_keys, pairs ? (void *)dev_values : nullptr, (uint64_t)key_count, dev_sorted_keys_out,
+                               pairs ? (void *)dev_sorted_values_out : nullptr, (int)sizeof(KeyT), vb, &sk, &sv,
+                               gpusort::KeyTraits<KeyT>::type, stream, 1);
         (void)hipFree(temp);
         if (err != 0) {
             gpusort::report_failure("rdxsrt_unstable_sort (64-bit path)", err);
             return RDXSRT_SortedSequence<KeyT, ValueT>{nullptr, nullptr};
         }
-        return RDXSRT_SortedSequence<KeyT, ValueT>{reinterpret_cast<KeyT *>(k2[sel]),
-                                                   pairs ? reinterpret_cast<ValueT *>(v2[sel]) : nullptr};
+        return RDXSRT_SortedSequence<KeyT, ValueT>{reinterpret_cast<KeyT *>(sk), pairs ? reinterpret_cast<ValueT *>(sv) : nullptr};
     } else {
     RDXSRT_GPUDataManager *dm = pre_allocated_dm ? pre_allocated_dm : new RDXSRT_GPUDataManager((uint64_t)key_count, pairs);
     uint32_t *sk = nullptr, *sv = nullptr;

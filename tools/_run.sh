@@ -1,5 +1,4 @@
-python tools/kprof.py 30 keys msb zipf 2>&1 | grep -E "sum|histogram|upsweep"
-python tools/kprof.py 30 keys msb uniform 2>&1 | grep -E "sum|histogram|upsweep"
-python tools/kprof.py 30 keys lsb zipf 2>&1 | grep -E "sum|upsweep"
-python tools/kprof.py 30 keys lsb uniform 2>&1 | grep -E "sum|upsweep"
-python tools/dist_bench.py 28 2>&1 | grep -v amdgpu.ids
+python tools/wide_msb_bench.py 28 2>&1 | grep -v amdgpu
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r2_wide_prof -- python3 $GRAFT_REPO_ROOT/tools/wide_msb_bench.py 26 > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT; find gpurun_out/r2_wide_prof -name "*kernel_trace.csv" -delete; head -20 $(find gpurun_out/r2_wide_prof -name "*kernel_stats.csv" | head -1) | cut -c1-160
