@@ -28,7 +28,7 @@ int main(int argc, char **argv)
     if (pairs) OK(rocprim::radix_sort_pairs(nullptr, tb, a, b, va, vb, n, 0, 32));
     else OK(rocprim::radix_sort_keys(nullptr, tb, a, b, n, 0, 32));
     void *temp; OK(hipMalloc(&temp, tb));
-    float best = 1e9f;
+    float best = 1e9f, best_db = 1e9f;
     for (int it = 0; it < 4; ++it) {
         OK(hipMemcpy(a, src, n * 4, hipMemcpyDeviceToDevice));
         if (pairs) OK(gs_generate_u32(va, n, GS_GEN_ENUMERATED, 0, 0, 1, nullptr));
@@ -42,6 +42,39 @@ int main(int argc, char **argv)
     }
     printf("rocprim::radix_sort_%s  2^%d u32: %.3f ms  %.2f G%s/s  (temp %.0f MiB)\n", pairs ? "pairs" : "keys", log2n, best,
            n / best / 1e6, pairs ? "pairs" : "keys", tb / 1048576.0);
+
+    // like for like with gs_lsb_sort_u32's DoubleBuffer form: rocprim::double_buffer (both halves may be overwritten, no
+    // internal ping-pong copy of the input)
+    {
+        size_t tb2 = 0;
+        rocprim::double_buffer<uint32_t> dk(a, b), dv(va, vb);
+        if (pairs) OK(rocprim::radix_sort_pairs(nullptr, tb2, dk, dv, n, 0, 32));
+        else OK(rocprim::radix_sort_keys(nullptr, tb2, dk, n, 0, 32));
+        void *temp2; OK(hipMalloc(&temp2, tb2 ? tb2 : 1));
+        float best2 = 1e9f;
+        for (int it = 0; it < 4; ++it) {
+            rocprim::double_buffer<uint32_t> k2(a, b), v2(va, vb);
+            OK(hipMemcpy(a, src, n * 4, hipMemcpyDeviceToDevice));
+            if (pairs) OK(gs_generate_u32(va, n, GS_GEN_ENUMERATED, 0, 0, 1, nullptr));
+            OK(hipDeviceSynchronize());
+            OK(hipEventRecord(e0));
+            if (pairs) OK(rocprim::radix_sort_pairs(temp2, tb2, k2, v2, n, 0, 32));
+            else OK(rocprim::radix_sort_keys(temp2, tb2, k2, n, 0, 32));
+            OK(hipEventRecord(e1)); OK(hipEventSynchronize(e1));
+            float ms; OK(hipEventElapsedTime(&ms, e0, e1));
+            if (it > 0 && ms < best2) best2 = ms;
+        }
+        printf("rocprim::radix_sort_%s (double_buffer form) 2^%d u32: %.3f ms  %.2f G%s/s  (temp %.0f MiB)\n", pairs ? "pairs" : "keys",
+               log2n, best2, n / best2 / 1e6, pairs ? "pairs" : "keys", tb2 / 1048576.0);
+        best_db = best2;
+        OK(hipFree(temp2));
+        // leave the non-overwriting form's output in b / vb for the cross-check below
+        OK(hipMemcpy(a, src, n * 4, hipMemcpyDeviceToDevice));
+        if (pairs) OK(gs_generate_u32(va, n, GS_GEN_ENUMERATED, 0, 0, 1, nullptr));
+        if (pairs) OK(rocprim::radix_sort_pairs(temp, tb, a, b, va, vb, n, 0, 32));
+        else OK(rocprim::radix_sort_keys(temp, tb, a, b, n, 0, 32));
+        OK(hipDeviceSynchronize());
+    }
 
     // libgpusort on the same input
     const size_t gtb = gs_lsb_temp_bytes(n, pairs);
@@ -62,8 +95,8 @@ int main(int argc, char **argv)
         float ms; OK(hipEventElapsedTime(&ms, e0, e1));
         if (it > 0 && ms < gbest) gbest = ms;
     }
-    printf("gs_lsb_sort_u32           2^%d u32: %.3f ms  %.2f G%s/s  -> %.2fx\n", log2n, gbest, n / gbest / 1e6,
-           pairs ? "pairs" : "keys", best / gbest);
+    printf("gs_lsb_sort_u32 (DoubleBuffer form) 2^%d u32: %.3f ms  %.2f G%s/s  -> %.2fx rocprim's double_buffer form, %.2fx its "
+           "non-overwriting form\n", log2n, gbest, n / gbest / 1e6, pairs ? "pairs" : "keys", best_db / gbest, best / gbest);
     // bit-exact cross-check on a sample (whole arrays up to 2^28)
     const size_t m = n <= ((size_t)1 << 28) ? n : ((size_t)1 << 28);
     std::vector<uint32_t> x(m), y(m);
