@@ -1,2 +1,1 @@
-tools/compare/rocprim_sort 30 2>&1 | tail -4
-tools/compare/rocprim_sort 30 pairs 2>&1 | tail -5
+GS_LIB_PATH=$PWD/gpu-sort_amd/lib/libgpusort_smallup.so python tools/kprof.py 30 2>&1 | grep -E "upsweep|other|sum"
