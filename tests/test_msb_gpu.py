@@ -118,6 +118,34 @@ def test_signed_and_float_keys(gs, cuda, oracle):
     assert np.all(got[1:] >= got[:-1]) and np.array_equal(np.sort(got.view(np.uint32)), np.sort(f.view(np.uint32)))
 
 
+@pytest.mark.parametrize("share", [0.55, 0.9, 0.999])
+def test_heavy_hitter_path_signed_and_float_keys(gs, cuda, oracle, share):
+    """The heavy-hitter path writes the dominant VALUE itself into the result (not a moved key): for signed and float keys
+    that is the un-transformed value, also where the bucket already lies in the result buffer.  One value (negative)
+    holds `share` of the keys at levels 1 and 2; the census must show the path was taken."""
+    from gpu_sort_amd.msb import msb_census
+    n = (1 << 21) + 4321
+    rng = np.random.default_rng(int(share * 1000))
+    noise = oracle.gen_uniform(n, seed=3)
+    hot = rng.random(n) < share
+    for kt, hotval, view in ((gs.GS_KEY_I32, np.int32(-123456789).view(np.uint32), np.int32),
+                             (gs.GS_KEY_F32, np.float32(-3.75e-3).view(np.uint32), np.float32),
+                             (gs.GS_KEY_U32, np.uint32(0xC0FFEE11), np.uint32)):
+        raw = np.where(hot, hotval, noise).astype(np.uint32)
+        if view is np.float32:
+            f = raw.view(np.float32).copy()
+            f[np.isnan(f)] = 1.5
+            raw = f.view(np.uint32)
+        dk, alt = to_dev(raw, cuda), torch.empty(n, dtype=torch.int32, device=cuda)
+        dm = torch.empty(gs.lib.gs_msb_temp_bytes(n, 0), dtype=torch.uint8, device=cuda)
+        seq = gs.rdxsrt_unstable_sort(dk, None, n, alt, None, pre_allocated_dm=dm, key_type=kt)
+        got = to_u32(seq.sorted_keys).view(view)
+        assert np.all(got[1:] >= got[:-1])
+        assert np.array_equal(np.sort(got.view(np.uint32)), np.sort(raw))
+        cen = msb_census(dm, n)
+        assert sum(c["pivot_keys"] for c in cen) >= int(share * n * 0.99)
+
+
 def test_host_pointer_wrappers(gs, cuda, oracle):
     """rdxsrt_unstable_sort_keys / _pairs (gpu_radix_sort.h:511-587): host arrays in and out."""
     n = 123457
