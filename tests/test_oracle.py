@@ -202,3 +202,41 @@ def test_twiddles_64bit_are_order_preserving(oracle):
     t = [L.orc_twiddle_in_i64(int(x)) for x in i.view(np.uint64)]
     assert t == sorted(t)
     assert L.orc_twiddle_in_u64(12345) == 12345
+
+
+def test_msb_classification_oracle_invariants(oracle):
+    """oracle.msb_level_lists (the CPU restatement of row M4 the GPU classification is compared with): at every level the
+    buckets passed on and the tasks emitted tile exactly the keys of the level's buckets; every task fits its class and no
+    smaller one; a merged task (more bits than the level leaves) is below the merge threshold; a passed-on bucket exceeds
+    the largest local capacity; the heavy-hitter rule only fires on buckets one value dominates."""
+    caps = oracle.MSB_CLASS_CAPS
+    n = (1 << 21) + 123
+    for keys in (oracle.gen_uniform(n, seed=3), oracle.gen_zipf(n, seed=4), oracle.gen_entropy_and(n, 4, seed=5)):
+        covered_prev = n
+        for level in range(3):
+            rb = 24 - 8 * level
+            buckets, tasks = oracle.msb_level_lists(keys, level, pivot=False)
+            in_tasks = sum(s for c in tasks.values() for _, s, _ in c)
+            in_buckets = sum(s for _, s in buckets)
+            assert in_tasks + in_buckets == covered_prev            # nothing lost, nothing counted twice
+            for c, ts in tasks.items():
+                for off, size, bits in ts:
+                    assert size <= caps[c] and (c == 0 or size > caps[c - 1])
+                    assert bits in (rb, rb + 8)
+                    if bits == rb + 8:
+                        assert size < oracle.MSB_MERGE
+            assert all(s > caps[-1] for _, s in buckets)
+            ranges = sorted([(o, s) for o, s in buckets] + [(o, s) for c in tasks.values() for o, s, _ in c])
+            assert all(a[0] + a[1] <= b[0] for a, b in zip(ranges, ranges[1:]))   # disjoint
+            covered_prev = in_buckets
+            if not buckets:
+                break
+    # heavy-hitter rule: a bucket with one value on 97 % of its keys is taken (the three-sample candidate misses a 97 %
+    # value with probability 0.003; the seed below does not), one with 30 % is not, whatever the samples say
+    rng = np.random.default_rng(1)
+    base = (oracle.gen_uniform(60000, seed=9) & np.uint32(0x0000ffff)) | np.uint32(0x12340000)
+    hot = base.copy(); hot[rng.random(60000) < 0.97] = np.uint32(0x12345678)
+    cold = base.copy(); cold[rng.random(60000) < 0.3] = np.uint32(0x12345678)
+    got = oracle.msb_heavy_hitter(hot)
+    assert got is not None and got[0] == 0x12345678 and got[1] + got[2] <= 60000 and got[2] == int((hot == 0x12345678).sum())
+    assert oracle.msb_heavy_hitter(cold) is None
