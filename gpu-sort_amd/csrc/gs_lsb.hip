@@ -315,7 +315,8 @@ __device__ __forceinline__ void downsweep_tile(DownsweepSmem<HAS_VALUES> &sm, co
 {
     constexpr bool ALLWAVE = HAS_VALUES;   // see step 3
 
-    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    [[maybe_unused]] const int tid = threadIdx.x;
+    const int lane = lane_id(), w = wave_id();
     const uint32_t full_tiles = p.n / (uint32_t)LSB_TILE;
     auto tw_in = [&](uint32_t k) { return TW == 0 ? k : twiddle_in(k, TW == 2 ? p.f32_in : 0, p.xor_in); };
     auto tw_out = [&](uint32_t k) { return TW == 0 ? k : twiddle_out(k, TW == 2 ? p.f32_out : 0, p.xor_out); };

@@ -539,7 +539,7 @@ __device__ __forceinline__ void msb_scatter_tile(ScatterSmem<HAS_VALUES, REMAP> 
     constexpr bool small = !BIG;                     // n <= 2^30: 32-bit byte offsets into the output
     constexpr bool ALLWAVE = HAS_VALUES && !REMAP;   // with the 4 KiB remap table the extra rows would cost a block per CU
     constexpr int ESH = HAS_VALUES ? 3 : 2;           // log2 of a staged element's size
-    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int lane = lane_id(), w = wave_id();
     uint32_t *my = sm.whist[w];
     const uint16_t *mybase = sm.wbase[ALLWAVE ? w : 0];
     const uint32_t wbase = (uint32_t)w * (WAVE * MSB_KPT) + lane;

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(W_THREADS, 4) void wide_downsweep_kernel(const K *_
     __shared__ __attribute__((aligned(16))) unsigned char stage_raw[W_TILE * ELEM];
     K *stage_k = reinterpret_cast<K *>(stage_raw);
 
-    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int lane = lane_id(), w = wave_id();
     const uint32_t t = tile_of_item(blockIdx.x, p.num_tiles);   // XCD-contiguous slices: neighbouring runs meet in one L2
     const uint64_t tile_base = (uint64_t)t * W_TILE;
     const uint32_t valid = (p.n - tile_base < (uint64_t)W_TILE) ? (uint32_t)(p.n - tile_base) : (uint32_t)W_TILE;
