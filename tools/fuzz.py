@@ -162,6 +162,21 @@ def wide_case(it):
         fail("wide keys", **case)
     if dv is not None and not torch.equal(dv.Current()[:n], vals[perm]):
         fail("wide values (stability)", **case)
+    # the same keys through the MSB path's wide kernel set (gs_msb_sort_wide: all key bits, ascending, unstable: values
+    # may be permuted inside runs of equal keys only)
+    from gpu_sort_amd.msb import rdxsrt_unstable_sort_wide
+    mk, mv = keys.clone(), (vals.clone() if vals is not None else None)
+    seq, _ = rdxsrt_unstable_sort_wide(mk, mv, n, torch.empty_like(mk), torch.empty_like(mv) if mv is not None else None, key_type=ktid)
+    full = torch.sort(img, stable=True)[1]
+    if not torch.equal(seq.sorted_keys[:n], keys[full]):
+        fail("wide MSB keys", **case)
+    if mv is not None:
+        def canon(order_img, v):      # values sorted inside every run of equal keys
+            i1 = torch.sort(v.to(torch.int64), stable=True)[1]
+            i2 = torch.sort(order_img[i1], stable=True)[1]
+            return v[i1][i2]
+        if not torch.equal(canon(img[full], seq.sorted_values[:n]), canon(img[full], vals[full])):
+            fail("wide MSB values", **case)
 
 
 def shard_case(it):
