@@ -50,6 +50,8 @@ SIGNATURES = {
                                 C.POINTER(C.c_uint32), vp]),
     "gs_segmented_temp_bytes": (sz, [u64, i32, C.c_uint32]),
     "gs_segmented_sort_u32": (i32, [vp, sz, pp, pp, C.POINTER(i32), u64, C.c_uint32, vp, vp, i32, i32, i32, i32, vp]),
+    "gs_segmented_wide_temp_bytes": (sz, [u64, i32, i32, C.c_uint32]),
+    "gs_segmented_sort_wide": (i32, [vp, sz, pp, pp, C.POINTER(i32), u64, C.c_uint32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "gs_msb_first_pass_u32": (i32, [vp, sz, vp, vp, vp, vp, u64, i32, vp, vp]),
     "gs_msb_finish_temp_bytes": (sz, [u64, i32, i32]),
     "gs_msb_finish_u32": (i32, [vp, sz, vp, vp, vp, vp, u64, vp, i32, i32, vp, i32]),

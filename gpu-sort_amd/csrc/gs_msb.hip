@@ -1460,6 +1460,47 @@ int small_stable_sort(void *scratch, size_t scratch_bytes, const uint32_t *kin, 
 }
 
 
+// ---- segmented sort (SURVEY.md 8f item 4; cub::DeviceSegmentedRadixSort, dispatch_radix_sort.cuh:321-432)
+// Segments that fit a workgroup become stable local-sort tasks; the others become the buckets of ONE level
+// that is partitioned once per 8-bit digit, least significant first, with the level machinery above.
+__global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *__restrict__ seg_begin,
+                                                           const int *__restrict__ seg_end, uint32_t nseg, int nclass,
+                                                           uint32_t sort_bits, uint32_t shift0, uint32_t num_items)
+{
+    const uint32_t cap_max = ws.caps[nclass - 1];
+    for (uint32_t base = blockIdx.x * blockDim.x; base < nseg; base += gridDim.x * blockDim.x) {
+        const uint32_t sg = base + threadIdx.x;
+        uint32_t b = 0, size = 0;
+        if (sg < nseg) {
+            int lo = seg_begin[sg], hi = seg_end[sg];
+            // offsets outside [0, num_items] are the caller's error; clamp them so that they cannot become
+            // out-of-bounds accesses
+            if (lo < 0) lo = 0;
+            if (hi > (int)num_items) hi = (int)num_items;
+            if (hi > lo) { b = (uint32_t)lo; size = (uint32_t)(hi - lo); }
+        }
+        int cls = -1;
+        if (size != 0 && size <= cap_max) { cls = 0; while (ws.caps[cls] < size) ++cls; }
+        // one global atomic per wave and class
+#pragma unroll
+        for (int c = 0; c < MSB_NCLASS; ++c) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == c);
+            if (m == 0) continue;
+            uint32_t first = 0;
+            if (count_lower_mask(m) == 0 && cls == c) first = atomicAdd(&ws.level[1].task_count[c], (uint32_t)__popcll(m));
+            first = (uint32_t)__shfl((int)first, __builtin_ctzll(m), WAVE);
+            if (cls == c && first + count_lower_mask(m) < ws.max_tasks)
+                ws.tasks[c][first + count_lower_mask(m)] = MsbTask{b, size, sort_bits, shift0};
+        }
+        if (size > cap_max) {
+            const uint32_t tiles = ws_tiles_of(ws, size);
+            const unsigned long long old = atomicAdd(&ws.level[1].packed, (1ull << 32) | tiles);
+            if ((uint32_t)(old >> 32) < ws.max_buckets) ws.buckets[1][(uint32_t)(old >> 32)] = MsbBucket{b, size, (uint32_t)old, tiles};
+        }
+    }
+}
+
+
 // ================================================================ wide MSB ==
 // rdxsrt_unstable_sort for 64-bit keys and / or 64-bit values: the reference instantiates its hybrid sort for 8-byte keys
 // and values too (RadixSortConfig<8,*>, msb/src/sort/gpu_sort_config.h:179-198; msb/tests/test_sort_keys.cu:154-195,
@@ -1486,7 +1527,7 @@ template <typename K> __device__ __forceinline__ K mw_tw_out(K k, int f, uint64_
 
 template <typename K>
 __global__ __launch_bounds__(MW_THREADS) void mw_upsweep_kernel(MsbWs ws, int L, const K *__restrict__ src, uint32_t shift, int f_in,
-                                                                uint64_t xor_in)
+                                                                uint64_t xor_in, uint32_t mask = 0xffu)
 {
     __shared__ uint32_t lh[MW_WAVES][RADIX];
     uint32_t ntiles = (uint32_t)ws.level[L].packed;
@@ -1512,7 +1553,7 @@ __global__ __launch_bounds__(MW_THREADS) void mw_upsweep_kernel(MsbWs ws, int L,
                 }
 #pragma unroll
                 for (int u = 0; u < BATCH; ++u)
-                    if (j + u * WAVE + lane < T.valid) hist_add(my, (uint32_t)(mw_tw_in<K>(v[u], f_in, xor_in) >> shift) & 0xffu);
+                    if (j + u * WAVE + lane < T.valid) hist_add(my, (uint32_t)(mw_tw_in<K>(v[u], f_in, xor_in) >> shift) & mask);
             }
         }
         __syncthreads();
@@ -1576,7 +1617,7 @@ __device__ __forceinline__ void mw_scan_rows(uint32_t (*whist)[RADIX], uint32_t 
 template <typename K, typename V>
 __global__ __launch_bounds__(MW_THREADS, 4) void mw_scatter_kernel(MsbWs ws, int L, const K *__restrict__ src_k, K *__restrict__ dst_k,
                                                                    const V *__restrict__ src_v, V *__restrict__ dst_v, uint32_t shift,
-                                                                   int f_in, uint64_t xor_in)
+                                                                   int f_in, uint64_t xor_in, uint32_t mask = 0xffu)
 {
     constexpr bool HAS_VALUES = !std::is_same<V, MwNoVal>::value;
     constexpr size_t ELEM = sizeof(K) > (HAS_VALUES ? sizeof(V) : 1) ? sizeof(K) : sizeof(V);
@@ -1609,7 +1650,7 @@ __global__ __launch_bounds__(MW_THREADS, 4) void mw_scatter_kernel(MsbWs ws, int
         const uint32_t idx = wbase + i * WAVE;
         key[i] = pk[idx < valid ? idx : valid - 1u];
     }
-    auto digit_of = [&](K k) { return (uint32_t)(mw_tw_in<K>(k, f_in, xor_in) >> shift) & 0xffu; };
+    auto digit_of = [&](K k) { return (uint32_t)(mw_tw_in<K>(k, f_in, xor_in) >> shift) & mask; };
 #pragma unroll
     for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
     mw_rank<MW_KPT>(my, pos, [&](int i) { return (wbase + i * WAVE < valid) ? digit_of(key[i]) : 255u; });
@@ -1687,17 +1728,20 @@ __global__ __launch_bounds__(MW_THREADS, KPT > 8 ? 2 : 4) void mw_local_sort_ker
             key[i] = idx < size ? k : (K) ~(K)0;
             if constexpr (HAS_VALUES) val[i] = src_v[T.offset + (idx < size ? idx : last)];
         }
+        // the task's bits start at bit `pad` of the key (0 in the MSB sort, begin_bit in a segmented sort); the last digit
+        // may be narrower than 8 bits.  Pads are all-ones keys: the widest digit value in every pass, so they rank last.
 #pragma unroll 1
-        for (uint32_t shift = 0; shift < T.sort_bits; shift += 8) {
+        for (uint32_t done = 0; done < T.sort_bits; done += 8) {
+            const uint32_t shift = T.pad + done, dm = (T.sort_bits - done < 8u) ? ((1u << (T.sort_bits - done)) - 1u) : 0xffu;
 #pragma unroll
             for (int i = lane; i < RADIX; i += WAVE) my[i] = 0;
-            mw_rank<KPT>(my, pos, [&](int i) { return (uint32_t)(key[i] >> shift) & 0xffu; });
+            mw_rank<KPT>(my, pos, [&](int i) { return (uint32_t)(key[i] >> shift) & dm; });
             __syncthreads();
             if (w == 0) { uint32_t ex[4]; mw_scan_rows<MW_WAVES>(whist, ex); }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
-                pos[i] += my[(uint32_t)(key[i] >> shift) & 0xffu];
+                pos[i] += my[(uint32_t)(key[i] >> shift) & dm];
                 stage_k[pos[i]] = key[i];
             }
             __syncthreads();
@@ -1793,6 +1837,60 @@ static int msb_wide_sort(void *d_temp, K *keys, V *vals, uint64_t num_items, K *
           hipLaunchKernelGGL((mw_scatter_kernel<K, V>), dim3(max_tiles), dim3(MW_THREADS), 0, s, ws, L, sk, dk, sv, dv, shift, f, x); }
         if (!last) mw_launch_local_sorts<K, V>(ws, L, (const K *)dk, buf_k[0], (const V *)dv, buf_v[0], f, x, s);
     }
+    return (int)hipGetLastError();
+}
+
+// cub::DeviceSegmentedRadixSort for the wide element types (dispatch_radix_sort.cuh:321-432 is type-generic): the structure
+// of gs_segmented_sort_u32 with the wide kernel set -- segments of <= 8192 elements become stable local-sort tasks, the larger
+// ones the buckets of one level that is partitioned once per 8-bit digit from begin_bit up (keys stay in the caller's
+// representation, so there is no first / last pass distinction).
+template <typename K, typename V>
+static int seg_wide_sort(void *d_temp, void *d_keys[2], void *d_vals[2], int *selector, uint64_t num_items, uint32_t num_segments,
+                         const int32_t *d_begin_offsets, const int32_t *d_end_offsets, int begin_bit, int end_bit, int descending,
+                         int key_type, hipStream_t s)
+{
+    constexpr bool pairs = !std::is_same<V, MwNoVal>::value;
+    constexpr int KB = (int)sizeof(K), nclass = 2;
+    const MsbWs ws = msb_carve(d_temp, num_items, pairs, 0, num_segments, MW_CAP, (uint32_t)(8 * KB));
+    const int num_bits = end_bit - begin_bit, passes = (num_bits + RADIX_BITS - 1) / RADIX_BITS;
+    const int sel = *selector, fin = sel ^ (passes & 1);
+    const bool is_float = key_type == GS_KEY_F32 || key_type == GS_KEY_F64;
+    const bool is_signed = key_type == GS_KEY_I32 || key_type == GS_KEY_I64;
+    const int f = is_float ? 1 : 0;
+    const uint64_t ones = KB == 8 ? ~0ull : 0xffffffffull;
+    const uint64_t x = (is_signed ? (KB == 8 ? 0x8000000000000000ull : 0x80000000ull) : 0ull) ^ (descending ? ones : 0ull);
+    hipError_t e = zero_async(ws.level, MSB_LEVELS * sizeof(MsbLevel), s);
+    if (e != hipSuccess) return (int)e;
+    { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
+      const uint32_t g = (num_segments + 255u) / 256u;
+      hipLaunchKernelGGL(seg_classify_kernel, dim3(g < 4096u ? g : 4096u), dim3(256), 0, s, ws, d_begin_offsets, d_end_offsets,
+                         num_segments, nclass, (uint32_t)num_bits, (uint32_t)begin_bit, (uint32_t)num_items); }
+    mw_launch_local_sorts<K, V>(ws, 1, (const K *)d_keys[sel], (K *)d_keys[fin], pairs ? (const V *)d_vals[sel] : nullptr,
+                                pairs ? (V *)d_vals[fin] : nullptr, f, x, s);
+    const uint32_t max_b = ws.max_buckets;
+    const uint32_t tiles_ub = (uint32_t)(num_items / MW_TILE) + max_b;
+    { KernelTimer kt(GS_K_MSB_HISTOGRAM, s);
+      hipLaunchKernelGGL(msb_expand_kernel, dim3(max_b < 4096u ? max_b : 4096u), dim3(256), 0, s, ws, 1, (const uint32_t *)nullptr); }
+    for (int p = 0; p < passes; ++p) {
+        const uint32_t shift = (uint32_t)(begin_bit + p * RADIX_BITS);
+        const int bits = (end_bit - (int)shift < RADIX_BITS) ? end_bit - (int)shift : RADIX_BITS;
+        const uint32_t mask = (1u << bits) - 1u;
+        const K *sk = (const K *)d_keys[sel ^ (p & 1)];
+        K *dk = (K *)d_keys[sel ^ ((p + 1) & 1)];
+        const V *sv = pairs ? (const V *)d_vals[sel ^ (p & 1)] : nullptr;
+        V *dv = pairs ? (V *)d_vals[sel ^ ((p + 1) & 1)] : nullptr;
+        { KernelTimer kt(GS_K_MSB_HISTOGRAM, s);
+          const uint32_t hg_ub = tiles_ub / MW_WAVES + 1;
+          hipLaunchKernelGGL((mw_upsweep_kernel<K>), dim3(hg_ub < MSB_MAX_GRID ? hg_ub : MSB_MAX_GRID), dim3(MW_THREADS), 0, s, ws, 1, sk,
+                             shift, f, x, mask);
+          hipLaunchKernelGGL(msb_scan_kernel, dim3(RADIX), dim3(1024), 0, s, ws, 1); }
+        { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
+          hipLaunchKernelGGL((msb_classify_kernel<true, false>), dim3(max_b < 4096u ? max_b : 4096u), dim3(256), 0, s, ws, 1,
+                             (const uint32_t *)nullptr, nclass); }
+        { KernelTimer kt(GS_K_MSB_PARTITION, s);
+          hipLaunchKernelGGL((mw_scatter_kernel<K, V>), dim3(tiles_ub), dim3(MW_THREADS), 0, s, ws, 1, sk, dk, sv, dv, shift, f, x, mask); }
+    }
+    *selector = fin;
     return (int)hipGetLastError();
 }
 
@@ -1946,46 +2044,6 @@ int gs_msb_read_lists(void *d_temp, uint64_t num_items, int has_values, int leve
         }
     }
     return hipSuccess;
-}
-
-// ---- segmented sort (SURVEY.md 8f item 4; cub::DeviceSegmentedRadixSort, dispatch_radix_sort.cuh:321-432)
-// Segments that fit a workgroup become stable local-sort tasks; the others become the buckets of ONE level
-// that is partitioned once per 8-bit digit, least significant first, with the level machinery above.
-__global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *__restrict__ seg_begin,
-                                                           const int *__restrict__ seg_end, uint32_t nseg, int nclass,
-                                                           uint32_t sort_bits, uint32_t shift0, uint32_t num_items)
-{
-    const uint32_t cap_max = msb_class_cap(nclass - 1);
-    for (uint32_t base = blockIdx.x * blockDim.x; base < nseg; base += gridDim.x * blockDim.x) {
-        const uint32_t sg = base + threadIdx.x;
-        uint32_t b = 0, size = 0;
-        if (sg < nseg) {
-            int lo = seg_begin[sg], hi = seg_end[sg];
-            // offsets outside [0, num_items] are the caller's error; clamp them so that they cannot become
-            // out-of-bounds accesses
-            if (lo < 0) lo = 0;
-            if (hi > (int)num_items) hi = (int)num_items;
-            if (hi > lo) { b = (uint32_t)lo; size = (uint32_t)(hi - lo); }
-        }
-        int cls = -1;
-        if (size != 0 && size <= cap_max) { cls = 0; while (msb_class_cap(cls) < size) ++cls; }
-        // one global atomic per wave and class
-#pragma unroll
-        for (int c = 0; c < MSB_NCLASS; ++c) {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == c);
-            if (m == 0) continue;
-            uint32_t first = 0;
-            if (count_lower_mask(m) == 0 && cls == c) first = atomicAdd(&ws.level[1].task_count[c], (uint32_t)__popcll(m));
-            first = (uint32_t)__shfl((int)first, __builtin_ctzll(m), WAVE);
-            if (cls == c && first + count_lower_mask(m) < ws.max_tasks)
-                ws.tasks[c][first + count_lower_mask(m)] = MsbTask{b, size, sort_bits, shift0};
-        }
-        if (size > cap_max) {
-            const uint32_t tiles = msb_tiles_of(size);
-            const unsigned long long old = atomicAdd(&ws.level[1].packed, (1ull << 32) | tiles);
-            if ((uint32_t)(old >> 32) < ws.max_buckets) ws.buckets[1][(uint32_t)(old >> 32)] = MsbBucket{b, size, (uint32_t)old, tiles};
-        }
-    }
 }
 
 size_t gs_segmented_temp_bytes_impl(uint64_t num_items, int has_values, uint32_t num_segments)
@@ -2245,6 +2303,41 @@ int gs_shard_partition_u32(void *d_temp, size_t temp_bytes, const uint32_t *d_ke
     return (int)hipGetLastError();
 }
 
+
+size_t gs_segmented_wide_temp_bytes(uint64_t num_items, int /*key_bytes*/, int val_bytes, uint32_t num_segments)
+{
+    return msb_ws_bytes(num_items, val_bytes != 0, 0, num_segments, MW_CAP);
+}
+
+int gs_segmented_sort_wide(void *d_temp, size_t temp_bytes, void *d_keys[2], void *d_vals[2], int *selector, uint64_t num_items,
+                           uint32_t num_segments, const int32_t *d_begin_offsets, const int32_t *d_end_offsets, int key_bytes,
+                           int val_bytes, int begin_bit, int end_bit, int descending, int key_type, void *stream)
+{
+    GS_CLEAR_STALE_ERROR();
+    if (!selector || (*selector != 0 && *selector != 1) || !d_keys) return hipErrorInvalidValue;
+    if (key_bytes != 4 && key_bytes != 8) return hipErrorInvalidValue;
+    if (val_bytes != 0 && val_bytes != 4 && val_bytes != 8) return hipErrorInvalidValue;
+    if (key_bytes == 4 && val_bytes != 8) return hipErrorInvalidValue;          // (u32, none | u32) is gs_segmented_sort_u32's
+    if ((val_bytes != 0) != (d_vals != nullptr)) return hipErrorInvalidValue;
+    if (begin_bit < 0 || end_bit > 8 * key_bytes || begin_bit > end_bit) return hipErrorInvalidValue;
+    if (num_items >= (1ull << 31)) return hipErrorInvalidValue;                  // int offsets
+    const bool k64 = key_bytes == 8;
+    if (k64 ? (key_type < GS_KEY_U64 || key_type > GS_KEY_F64) : (key_type < GS_KEY_U32 || key_type > GS_KEY_F32)) return hipErrorInvalidValue;
+    if (num_items == 0 || num_segments == 0 || begin_bit == end_bit) return hipSuccess;
+    if (!d_begin_offsets || !d_end_offsets) return hipErrorInvalidValue;
+    if (!d_temp || temp_bytes < gs_segmented_wide_temp_bytes(num_items, key_bytes, val_bytes, num_segments)) return hipErrorInvalidValue;
+    if (!d_keys[0] || !d_keys[1] || (d_vals && (!d_vals[0] || !d_vals[1]))) return hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+#define GS_SW(K, V) return seg_wide_sort<K, V>(d_temp, d_keys, d_vals, selector, num_items, num_segments, d_begin_offsets, d_end_offsets, \
+                                                begin_bit, end_bit, descending, key_type, s)
+    if (k64) {
+        if (val_bytes == 0) GS_SW(uint64_t, MwNoVal);
+        if (val_bytes == 4) GS_SW(uint64_t, uint32_t);
+        GS_SW(uint64_t, uint64_t);
+    }
+    GS_SW(uint32_t, uint64_t);
+#undef GS_SW
+}
 
 size_t gs_msb_wide_temp_bytes(uint64_t num_items, int key_bytes, int val_bytes)
 {

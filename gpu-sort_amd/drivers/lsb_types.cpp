@@ -117,26 +117,27 @@ static int test_type(int max_items)
 }
 
 // segmented: random cut points (test_device_radix_sort.cu:1092-1100), std::stable_sort per segment on the host
-static int test_segmented(int n, int num_segments, bool descending)
+template <typename KeyT>
+static int test_segmented(int n, int num_segments, bool descending, const char *name)
 {
     std::mt19937_64 rng(99 + n + num_segments);
-    std::vector<unsigned int> h_keys(n);
-    for (auto &x : h_keys) x = (unsigned int)(rng() & rng());
+    std::vector<KeyT> h_keys(n);
+    for (auto &x : h_keys) x = (KeyT)(rng() & rng());
     std::vector<int> offs(num_segments + 1);
     offs[0] = 0; offs[num_segments] = n;
     for (int i = 1; i < num_segments; ++i) offs[i] = (int)(rng() % (unsigned long long)(n + 1));
     std::sort(offs.begin(), offs.end());
-    std::vector<unsigned int> want(h_keys);
+    std::vector<KeyT> want(h_keys);
     for (int i = 0; i < num_segments; ++i) {
-        if (descending) std::stable_sort(want.begin() + offs[i], want.begin() + offs[i + 1], std::greater<unsigned int>());
+        if (descending) std::stable_sort(want.begin() + offs[i], want.begin() + offs[i + 1], std::greater<KeyT>());
         else std::stable_sort(want.begin() + offs[i], want.begin() + offs[i + 1]);
     }
-    unsigned int *d_k[2]; int *d_offs;
-    HIP_OK(hipMalloc(&d_k[0], (size_t)n * 4)); HIP_OK(hipMalloc(&d_k[1], (size_t)n * 4));
+    KeyT *d_k[2]; int *d_offs;
+    HIP_OK(hipMalloc(&d_k[0], (size_t)n * sizeof(KeyT))); HIP_OK(hipMalloc(&d_k[1], (size_t)n * sizeof(KeyT)));
     HIP_OK(hipMalloc(&d_offs, (size_t)(num_segments + 1) * 4));
-    HIP_OK(hipMemcpy(d_k[0], h_keys.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_k[0], h_keys.data(), (size_t)n * sizeof(KeyT), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_offs, offs.data(), (size_t)(num_segments + 1) * 4, hipMemcpyHostToDevice));
-    gpusort::DoubleBuffer<unsigned int> keys(d_k[0], d_k[1]);
+    gpusort::DoubleBuffer<KeyT> keys(d_k[0], d_k[1]);
     void *d_temp = nullptr; size_t temp_bytes = 0;
     auto run = [&]() {
         return descending ? gpusort::DeviceSegmentedRadixSort::SortKeysDescending(d_temp, temp_bytes, keys, n, num_segments, d_offs, d_offs + 1)
@@ -146,10 +147,10 @@ static int test_segmented(int n, int num_segments, bool descending)
     HIP_OK(hipMalloc(&d_temp, temp_bytes ? temp_bytes : 1));
     HIP_OK(run());
     HIP_OK(hipDeviceSynchronize());
-    std::vector<unsigned int> out(n);
-    HIP_OK(hipMemcpy(out.data(), keys.Current(), (size_t)n * 4, hipMemcpyDeviceToHost));
-    const int bad = memcmp(out.data(), want.data(), (size_t)n * 4) != 0;
-    printf("segmented u32 keys, n=%d, %d segments, %s: %s\n", n, num_segments, descending ? "descending" : "ascending",
+    std::vector<KeyT> out(n);
+    HIP_OK(hipMemcpy(out.data(), keys.Current(), (size_t)n * sizeof(KeyT), hipMemcpyDeviceToHost));
+    const int bad = memcmp(out.data(), want.data(), (size_t)n * sizeof(KeyT)) != 0;
+    printf("segmented %s keys, n=%d, %d segments, %s: %s\n", name, n, num_segments, descending ? "descending" : "ascending",
            bad ? "FAIL" : "CORRECT");
     HIP_OK(hipFree(d_k[0])); HIP_OK(hipFree(d_k[1])); HIP_OK(hipFree(d_offs)); HIP_OK(hipFree(d_temp));
     return bad;
@@ -166,9 +167,12 @@ int main(int argc, char **argv)
     bad += test_type<unsigned long long, gpusort::NullType>(n);
     bad += test_type<long long, unsigned int>(n);
     bad += test_type<double, unsigned long long>(n);
-    bad += test_segmented(n, 1, false);
-    bad += test_segmented(n, 37, true);
-    bad += test_segmented(n, 5000, false);
+    bad += test_segmented<unsigned int>(n, 1, false, "u32");
+    bad += test_segmented<unsigned int>(n, 37, true, "u32");
+    bad += test_segmented<unsigned int>(n, 5000, false, "u32");
+    bad += test_segmented<unsigned long long>(n, 1, true, "u64");
+    bad += test_segmented<unsigned long long>(n, 37, false, "u64");
+    bad += test_segmented<long long>(n, 5000, true, "i64");
     printf("%s\n", bad ? "SOME CASES FAILED" : "ALL CORRECT");
     return bad ? 1 : 0;
 }

@@ -188,15 +188,19 @@ class DeviceSegmentedRadixSort:
     def _sort(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, num_segments, d_begin_offsets, d_end_offsets,
               begin_bit, end_bit, descending, stream, key_type):
         has_values = d_values is not None
-        need = lib.gs_segmented_temp_bytes(num_items, int(has_values), num_segments)
+        kb = d_keys.d_buffers[0].element_size()
+        vb = d_values.d_buffers[0].element_size() if has_values else 0
+        wide = kb == 8 or vb == 8            # the wide element types: gs_segmented_sort_wide
+        need = (lib.gs_segmented_wide_temp_bytes(num_items, kb, vb, num_segments) if wide
+                else lib.gs_segmented_temp_bytes(num_items, int(has_values), num_segments))
         if d_temp_storage is None:
             return need
         if end_bit is None:
-            end_bit = 32
+            end_bit = 8 * kb
         if key_type is None:
             key_type = _KEY_TYPES.get(d_keys.d_buffers[0].dtype, _lib.GS_KEY_U32)
         for b in d_keys.d_buffers:
-            _check_buf(b, num_items, "d_keys")
+            _check_buf(b, num_items, "d_keys", kb)
         for o in (d_begin_offsets, d_end_offsets):
             if not isinstance(o, torch.Tensor) or o.dtype != torch.int32 or not o.is_cuda or o.numel() < num_segments:
                 raise ValueError("segment offsets: expected int32 device tensors of >= num_segments entries")
@@ -204,9 +208,20 @@ class DeviceSegmentedRadixSort:
         vals = None
         if has_values:
             for b in d_values.d_buffers:
-                _check_buf(b, num_items, "d_values")
+                _check_buf(b, num_items, "d_values", vb)
             vals = (C.c_void_p * 2)(d_values.d_buffers[0].data_ptr(), d_values.d_buffers[1].data_ptr())
         sel = C.c_int(d_keys.selector)
+        if wide:
+            err = lib.gs_segmented_sort_wide(C.c_void_p(d_temp_storage.data_ptr()),
+                                             min(temp_storage_bytes, d_temp_storage.numel() * d_temp_storage.element_size()),
+                                             keys, vals, C.byref(sel), num_items, num_segments,
+                                             C.c_void_p(d_begin_offsets.data_ptr()), C.c_void_p(d_end_offsets.data_ptr()),
+                                             kb, vb, begin_bit, end_bit, int(descending), key_type, _stream_ptr(stream))
+            check(err, "gs_segmented_sort_wide")
+            d_keys.selector = sel.value
+            if has_values:
+                d_values.selector = sel.value
+            return need
         err = lib.gs_segmented_sort_u32(C.c_void_p(d_temp_storage.data_ptr()),
                                         min(temp_storage_bytes, d_temp_storage.numel() * d_temp_storage.element_size()),
                                         keys, vals, C.byref(sel), num_items, num_segments,

@@ -210,6 +210,15 @@ int gs_segmented_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], 
                           const int32_t *d_begin_offsets, const int32_t *d_end_offsets, int begin_bit,
                           int end_bit, int descending, int key_type, void *stream);
 
+/* The same for the wider element types (64-bit keys: GS_KEY_U64 / I64 / F64, with no, 32-bit or 64-bit values; 32-bit keys
+ * with 64-bit values) -- cub's segmented dispatch is type-generic (dispatch_radix_sort.cuh:321-432).  Stable; bits
+ * [begin_bit, end_bit) of the key; segments of <= 8192 elements cost one read and one write.  num_items < 2^31.        */
+size_t gs_segmented_wide_temp_bytes(uint64_t num_items, int key_bytes, int val_bytes, uint32_t num_segments);
+int gs_segmented_sort_wide(void *d_temp, size_t temp_bytes, void *d_keys[2], void *d_vals[2], int *selector,
+                           uint64_t num_items, uint32_t num_segments, const int32_t *d_begin_offsets,
+                           const int32_t *d_end_offsets, int key_bytes, int val_bytes, int begin_bit, int end_bit,
+                           int descending, int key_type, void *stream);
+
 /* The MSB path cut at the exchange point (north_star: "a single RCCL all-to-all after the
  * first digit pass"): gs_msb_first_pass_u32 is the top-byte partition on its own -- keys (and
  * values) leave grouped by top byte in d_*_out, in their order-preserving u32 form, and

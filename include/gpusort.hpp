@@ -14,9 +14,9 @@
 // Supported key types: unsigned int, int, float (the graded configurations are u32) and,
 // through the DoubleBuffer overloads, unsigned long long, long long, double; value type:
 // any 4- or 8-byte trivially copyable type or NullType.  The plain-pointer (copy)
-// overloads are 32-bit only.  rdxsrt_unstable_sort with 64-bit keys or values is served by
-// the wide LSB sort (gs_lsb_sort_wide): the hybrid MSB kernels are 32-bit, and a stable result
-// is one of the results an unstable sort may return.
+// overloads are 32-bit only.  rdxsrt_unstable_sort with 64-bit keys or values goes through the
+// hybrid MSB path's wide kernel set (gs_msb_sort_wide), DeviceSegmentedRadixSort with them
+// through gs_segmented_sort_wide.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -176,30 +176,45 @@ struct DeviceRadixSort {
 };
 
 // cub::DeviceSegmentedRadixSort, DoubleBuffer overloads (lsb/cub/cub/device/device_segmented_radix_sort.cuh:
-// 266-289, 450-473, 607-629, 779-801): 32-bit keys, 32-bit values, int offsets.
+// 266-289, 450-473, 607-629, 779-801): 32- or 64-bit keys, 32- or 64-bit values, int offsets.
 struct DeviceSegmentedRadixSort {
     template <typename KeyT, typename ValueT>
     static hipError_t Dispatch(void *d_temp_storage, size_t &temp_storage_bytes, DoubleBuffer<KeyT> &d_keys,
                                DoubleBuffer<ValueT> *d_values, int num_items, int num_segments, const int *d_begin_offsets,
                                const int *d_end_offsets, int begin_bit, int end_bit, bool descending, hipStream_t stream)
     {
-        static_assert(sizeof(KeyT) == 4, "32-bit keys only");
-        static_assert(std::is_same<ValueT, NullType>::value || sizeof(ValueT) == 4, "32-bit values only");
-        const size_t need = gs_segmented_temp_bytes((uint64_t)num_items, d_values != nullptr, (uint32_t)num_segments);
+        constexpr bool keys_only = std::is_same<ValueT, NullType>::value;
+        constexpr int KB = (int)sizeof(KeyT), VB = keys_only ? 0 : (int)sizeof(ValueT);
+        static_assert(KB == 4 || KB == 8, "32- or 64-bit keys");
+        static_assert(VB == 0 || VB == 4 || VB == 8, "32- or 64-bit values");
+        constexpr bool wide = KB == 8 || VB == 8;
+        const int vb = d_values ? VB : 0;
+        const size_t need = wide ? gs_segmented_wide_temp_bytes((uint64_t)num_items, KB, vb, (uint32_t)num_segments)
+                                 : gs_segmented_temp_bytes((uint64_t)num_items, d_values != nullptr, (uint32_t)num_segments);
         if (d_temp_storage == nullptr) {
             temp_storage_bytes = need;
             return hipSuccess;
         }
-        uint32_t *keys[2] = {reinterpret_cast<uint32_t *>(d_keys.d_buffers[0]), reinterpret_cast<uint32_t *>(d_keys.d_buffers[1])};
-        uint32_t *vals[2] = {nullptr, nullptr};
-        if (d_values) {
-            vals[0] = reinterpret_cast<uint32_t *>(d_values->d_buffers[0]);
-            vals[1] = reinterpret_cast<uint32_t *>(d_values->d_buffers[1]);
-        }
         int sel = d_keys.selector;
-        const int err = gs_segmented_sort_u32(d_temp_storage, temp_storage_bytes, keys, d_values ? vals : nullptr, &sel,
-                                              (uint64_t)num_items, (uint32_t)num_segments, d_begin_offsets, d_end_offsets,
-                                              begin_bit, end_bit, descending ? 1 : 0, KeyTraits<KeyT>::type, stream);
+        int err;
+        if constexpr (wide) {
+            void *keys[2] = {d_keys.d_buffers[0], d_keys.d_buffers[1]};
+            void *vals[2] = {nullptr, nullptr};
+            if (d_values) { vals[0] = d_values->d_buffers[0]; vals[1] = d_values->d_buffers[1]; }
+            err = gs_segmented_sort_wide(d_temp_storage, temp_storage_bytes, keys, d_values ? vals : nullptr, &sel, (uint64_t)num_items,
+                                         (uint32_t)num_segments, d_begin_offsets, d_end_offsets, KB, vb, begin_bit, end_bit,
+                                         descending ? 1 : 0, KeyTraits<KeyT>::type, stream);
+        } else {
+            uint32_t *keys[2] = {reinterpret_cast<uint32_t *>(d_keys.d_buffers[0]), reinterpret_cast<uint32_t *>(d_keys.d_buffers[1])};
+            uint32_t *vals[2] = {nullptr, nullptr};
+            if (d_values) {
+                vals[0] = reinterpret_cast<uint32_t *>(d_values->d_buffers[0]);
+                vals[1] = reinterpret_cast<uint32_t *>(d_values->d_buffers[1]);
+            }
+            err = gs_segmented_sort_u32(d_temp_storage, temp_storage_bytes, keys, d_values ? vals : nullptr, &sel, (uint64_t)num_items,
+                                        (uint32_t)num_segments, d_begin_offsets, d_end_offsets, begin_bit, end_bit, descending ? 1 : 0,
+                                        KeyTraits<KeyT>::type, stream);
+        }
         if (err == 0) {
             d_keys.selector = sel;
             if (d_values) d_values->selector = sel;
