@@ -1,6 +1,6 @@
 """Per-level census of an MSB sort (buckets, tiles, local-sort tasks per class, flagged tasks) read back from
 the workspace after the call.  python tools/msb_census.py [log2n] [uniform|zipf] [pairs]"""
-import sys, os, struct
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import gpu_sort_amd as gs
@@ -18,11 +18,12 @@ temp = torch.zeros(nb, dtype=torch.uint8, device=dev)
 with gs.KernelProfile() as prof:
     gs.rdxsrt_unstable_sort(a, va, n, b, vb, pre_allocated_dm=temp)
     torch.cuda.synchronize()
-off = (gs.lib.gs_lsb_temp_bytes(n, int(pairs)) + 255) // 256 * 256
-raw = temp[off: off + 5 * 48].cpu().numpy().tobytes()
 print({k: round(v[0], 3) for k, v in prof.read().items()})
-for L in range(4):
-    packed, t0, t1, t2, t3, flagged, pb, pk, _ = struct.unpack_from("<Q6IQQ", raw, L * 48)
-    print(f"level {L}: buckets {packed >> 32:7d}  tiles {packed & 0xffffffff:8d} ({(packed & 0xffffffff) * 8192 / n:6.1%} of the keys)  "
-          f"heavy-hitter buckets {pb} ({pk / n:6.1%} of the keys)  "
-          f"tasks per class {[t0, t1, t2, t3]}  tasks left to the general plan: {'yes' if flagged else 'no'}")
+from gpu_sort_amd.msb import msb_census, msb_algorithmic_bytes
+census = msb_census(temp, n, pairs)
+for L, c in enumerate(census):
+    print(f"level {L}: buckets {c['buckets']:7d}  tiles {c['tiles']:8d}  keys {c['keys']:11d} ({c['keys'] / n:6.1%})  "
+          f"heavy-hitter buckets {c['pivot_buckets']} ({c['pivot_keys'] / n:6.1%} of the keys)  "
+          f"tasks per class {c['tasks']} ({c['task_keys'] / n:6.1%} of the keys)  "
+          f"tasks left to the general plan: {'yes' if c['flagged'] else 'no'}")
+print("algorithmic bytes:", msb_algorithmic_bytes(census, n, pairs))
