@@ -58,7 +58,9 @@ struct UpsweepSmem {
 };
 
 // Plain dword loads in batches beat 16-byte loads here (0.81 vs 0.84 ms at 2^30) and need no alignment.
-template <bool NEXT, bool PIPE>
+// PLAIN: the keys need no transform on the way in (u32 ascending, and every pass after the first: keys travel
+// twiddled between passes), so the full-tile path below is load, v_bfe, address, ds_add and nothing else.
+template <bool NEXT, bool PIPE, bool PLAIN = false>
 __device__ __forceinline__ void upsweep_chunk(UpsweepSmem<NEXT, PIPE> &sm, const uint32_t *__restrict__ keys, uint32_t chunk,
                                               uint32_t *__restrict__ spine, uint16_t *__restrict__ prefix16,
                                               uint32_t *__restrict__ cc, uint32_t *__restrict__ next_totals, const PassParams &p,
@@ -80,10 +82,36 @@ __device__ __forceinline__ void upsweep_chunk(UpsweepSmem<NEXT, PIPE> &sm, const
             hist_add(my, __builtin_amdgcn_ubfe(k, p.shift, p.bits));        // wave-private ds_add_u32
             if (NEXT) hist_add(sm.hist2[w], __builtin_amdgcn_ubfe(k, q.next_shift, q.next_bits));
         };
-        // batches of dword loads from clamped indices: one code path for full, partial and misaligned tiles
-        // (measured as fast as an unclamped unrolled variant; a loop of one guarded load per trip would pay
-        // one HBM round trip per 64 keys)
         constexpr int GB = UPSWEEP_BATCH;
+        if (!NEXT && !PIPE && len == (uint32_t)LSB_TILE) {
+            // full tile (all but the array's last one): no clamps, no guards, and the test for a digit shared by the
+            // whole wave (a hot bucket, constant high bytes: 64 lanes would queue on 4 counters) is made on two keys
+            // of the batch instead of on each -- 15 -> 4 vector instructions per key
+            uint32_t wbits = p.bits;
+            asm volatile("" : "+v"(wbits));   // v_bfe_u32 takes one scalar operand (the shift)
+            auto digit_of = [&](uint32_t raw) {
+                return __builtin_amdgcn_ubfe(PLAIN ? raw : twiddle_in(raw, p.f32_in, p.xor_in), p.shift, wbits);
+            };
+#pragma unroll 1
+            for (uint32_t j = 0; j < (uint32_t)LSB_TILE; j += GB * WAVE) {
+                const uint32_t *at = src + j + lane;
+                uint32_t v[GB];
+#pragma unroll
+                for (int u = 0; u < GB; ++u) v[u] = __builtin_nontemporal_load(at + u * WAVE);
+                const uint32_t da = digit_of(v[0]), db = digit_of(v[GB / 2]);
+                const bool hot = __builtin_amdgcn_ballot_w64(da == __builtin_amdgcn_readfirstlane(da)) == ~0ull ||
+                                 __builtin_amdgcn_ballot_w64(db == __builtin_amdgcn_readfirstlane(db)) == ~0ull;
+                if (hot) {
+#pragma unroll
+                    for (int u = 0; u < GB; ++u) hist_add(my, digit_of(v[u]));
+                } else {
+#pragma unroll
+                    for (int u = 0; u < GB; ++u) atomicAdd(&my[digit_of(v[u])], 1u);
+                }
+            }
+        } else {
+        // batches of dword loads from clamped indices: one code path for partial and misaligned tiles
+        // (a loop of one guarded load per trip would pay one HBM round trip per 64 keys)
         const uint32_t last = len - 1u;
 #pragma unroll 1
         for (uint32_t j = 0; j < len; j += GB * WAVE) {
@@ -97,6 +125,7 @@ __device__ __forceinline__ void upsweep_chunk(UpsweepSmem<NEXT, PIPE> &sm, const
 #pragma unroll
             for (int u = 0; u < GB; ++u)
                 if (j + u * WAVE + lane < len) count(v[u]);
+        }
         }
     }
     __syncthreads();
@@ -138,14 +167,17 @@ __device__ __forceinline__ void upsweep_chunk(UpsweepSmem<NEXT, PIPE> &sm, const
     }
 }
 
-template <bool NEXT>
+template <bool NEXT, bool PLAIN = false>
 __global__ __launch_bounds__(LSB_THREADS) void lsb_upsweep_kernel(const uint32_t *__restrict__ keys,
                                                                   uint32_t *__restrict__ spine,
                                                                   uint16_t *__restrict__ prefix16,
                                                                   uint32_t *__restrict__ next_totals, PassParams p, PipeParams q)
 {
+    // blocks are dispatched round-robin over the 8 XCDs; the blocks of one XCD take CONSECUTIVE chunks, so the 16 chunk
+    // totals that share a 64-byte line of a spine row are merged in one L2 instead of leaving eight L2s as partial
+    // lines (0.736 -> 0.708 ms per launch at 2^30 keys)
     __shared__ UpsweepSmem<NEXT, false> sm;
-    upsweep_chunk<NEXT, false>(sm, keys, blockIdx.x, spine, prefix16, nullptr, next_totals, p, q);
+    upsweep_chunk<NEXT, false, PLAIN>(sm, keys, chunk_of_block(blockIdx.x, p.grid), spine, prefix16, nullptr, next_totals, p, q);
 }
 
 // ---- small arrays (up to LSB_SMALL_TILES tiles): with one wave per tile a handful of waves would each
@@ -280,7 +312,7 @@ __device__ uint32_t gs_phase_buf[131072 * 16];   // [block][phase], n <= 2^30
 #define GS_PHASE(k)                                                                          \
     do {                                                                                     \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();                        \
-        if (tid == 0 && blockIdx.x < 131072u) gs_phase_buf[blockIdx.x * 16 + (k)] = (uint32_t)(now_ - tprev_); \
+        if (tid == 0 && t < 131072u) gs_phase_buf[t * 16 + (k)] = (uint32_t)(now_ - tprev_); \
         tprev_ = now_;                                                                       \
     } while (0)
 #define GS_PHASE_WAIT(what) asm volatile("s_waitcnt " what ::: "memory")
@@ -311,12 +343,12 @@ __device__ __forceinline__ void downsweep_tile(DownsweepSmem<HAS_VALUES> &sm, co
     const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint16_t *__restrict__ prefix16,
     const uint32_t *__restrict__ totals, const PassParams &p, const uint64_t *__restrict__ sc, uint32_t tag,
-    uint32_t *__restrict__ error_word)
+    uint32_t *__restrict__ error_word, const uint32_t tid_ = threadIdx.x)
 {
     constexpr bool ALLWAVE = HAS_VALUES;   // see step 3
 
-    [[maybe_unused]] const int tid = threadIdx.x;
-    const int lane = lane_id(), w = wave_id();
+    [[maybe_unused]] const int tid = (int)tid_;
+    const int lane = (int)(tid_ & 63u), w = (int)(tid_ >> 6);
     const uint32_t full_tiles = p.n / (uint32_t)LSB_TILE;
     auto tw_in = [&](uint32_t k) { return TW == 0 ? k : twiddle_in(k, TW == 2 ? p.f32_in : 0, p.xor_in); };
     auto tw_out = [&](uint32_t k) { return TW == 0 ? k : twiddle_out(k, TW == 2 ? p.f32_out : 0, p.xor_out); };
@@ -592,12 +624,19 @@ __device__ __forceinline__ void downsweep_tile(DownsweepSmem<HAS_VALUES> &sm, co
         }
     }
     GS_PHASE(7);                                   // store issue
+#ifdef GS_EXP_DRAIN
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // experiment: the wave stays until its stores are acknowledged
+#endif
     GS_PHASE_WAIT("vmcnt(0)");
     GS_PHASE(8);                                   // store drain
 #ifdef GS_EXP_PHASES
-    if (tid == 0 && blockIdx.x < 131072u) {        // clock calibration: shader clocks vs 100 MHz real time
-        gs_phase_buf[blockIdx.x * 16 + 9] = (uint32_t)(__builtin_amdgcn_s_memtime() - t0_);
-        gs_phase_buf[blockIdx.x * 16 + 10] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - r0_);
+    if (tid == 0 && t < 131072u) {                 // clock calibration: shader clocks vs 100 MHz real time; who and where
+        gs_phase_buf[t * 16 + 9] = (uint32_t)(__builtin_amdgcn_s_memtime() - t0_);
+        gs_phase_buf[t * 16 + 10] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - r0_);
+        gs_phase_buf[t * 16 + 11] = (uint32_t)r0_;
+        gs_phase_buf[t * 16 + 12] = blockIdx.x;
+        gs_phase_buf[t * 16 + 13] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+        gs_phase_buf[t * 16 + 14] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
     }
 #endif
 }
@@ -610,6 +649,30 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
 {
     __shared__ __attribute__((aligned(16))) DownsweepSmem<HAS_VALUES> sm;
     const uint32_t full_tiles = p.n / (uint32_t)LSB_TILE;
+#if defined(GS_EXP_TPB) || defined(GS_EXP_PERSIST)
+    // experiment builds only (profiles/r02_lsb_structure_experiments.txt): a block walks several tiles, plainly one after the other
+    if (!TAIL) {
+#ifdef GS_EXP_STAGGER
+        if (((blockIdx.x / 256u) % 3u) >= 1u) __builtin_amdgcn_s_sleep(GS_EXP_STAGGER);
+        if (((blockIdx.x / 256u) % 3u) >= 2u) __builtin_amdgcn_s_sleep(GS_EXP_STAGGER);
+#endif
+#ifdef GS_EXP_TPB
+        for (uint32_t j = 0; j < (uint32_t)GS_EXP_TPB; ++j) {
+            const uint32_t item = blockIdx.x * (uint32_t)GS_EXP_TPB + j;
+#else
+        for (uint32_t j = 0;; ++j) {
+            const uint32_t item = blockIdx.x + j * gridDim.x;
+#endif
+            if (item >= full_tiles) return;
+            uint32_t tz = threadIdx.x;            // opaque: nothing thread-derived stays live across tiles
+            asm volatile("" : "+v"(tz));
+            downsweep_tile<HAS_VALUES, TAIL, TW, BIG, false>(sm, tile_of_item(item, full_tiles), keys_in, keys_out, vals_in, vals_out,
+                                                             spine, prefix16, totals, p, nullptr, 0u, nullptr, tz);
+            __syncthreads();
+        }
+        return;
+    }
+#endif
     if (!TAIL && blockIdx.x >= full_tiles) return;
     const uint32_t t = TAIL ? full_tiles : tile_of_item(blockIdx.x, full_tiles);
     downsweep_tile<HAS_VALUES, TAIL, TW, BIG, false>(sm, t, keys_in, keys_out, vals_in, vals_out, spine, prefix16, totals, p,
@@ -861,8 +924,13 @@ LsbWorkspace lsb_carve(void *temp, uint64_t n)
 int lsb_upsweep(const uint32_t *keys, uint32_t *spine, uint16_t *prefix16, const PassParams &p, hipStream_t s)
 {
     KernelTimer kt(GS_K_LSB_UPSWEEP, s);
-    hipLaunchKernelGGL(lsb_upsweep_kernel<false>, dim3(p.grid), dim3(LSB_THREADS), 0, s, keys, spine, prefix16,
-                       (uint32_t *)nullptr, p, PipeParams{});
+    const dim3 grid(p.grid);
+    if (!p.f32_in && !p.xor_in)
+        hipLaunchKernelGGL((lsb_upsweep_kernel<false, true>), grid, dim3(LSB_THREADS), 0, s, keys, spine, prefix16,
+                           (uint32_t *)nullptr, p, PipeParams{});
+    else
+        hipLaunchKernelGGL((lsb_upsweep_kernel<false, false>), grid, dim3(LSB_THREADS), 0, s, keys, spine, prefix16,
+                           (uint32_t *)nullptr, p, PipeParams{});
     return (int)hipGetLastError();
 }
 
@@ -887,11 +955,18 @@ static void launch_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t
                              const uint16_t *prefix16, const uint32_t *totals, const PassParams &p, hipStream_t s)
 {
     const dim3 block(LSB_THREADS);
+#if defined(GS_EXP_TPB)
+    const dim3 grid((p.ds_grid + GS_EXP_TPB - 1) / GS_EXP_TPB);
+#elif defined(GS_EXP_PERSIST)
+    const dim3 grid(p.ds_grid < (uint32_t)GS_EXP_PERSIST ? p.ds_grid : (uint32_t)GS_EXP_PERSIST);
+#else
+    const dim3 grid(p.ds_grid);
+#endif
     if (vin)
-        hipLaunchKernelGGL((lsb_downsweep_kernel<true, false, TW, BIG>), dim3(p.ds_grid), block, 0, s, kin, kout, vin, vout,
+        hipLaunchKernelGGL((lsb_downsweep_kernel<true, false, TW, BIG>), grid, block, 0, s, kin, kout, vin, vout,
                            spine, prefix16, totals, p);
     else
-        hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, TW, BIG>), dim3(p.ds_grid), block, 0, s, kin, kout, vin, vout,
+        hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, TW, BIG>), grid, block, 0, s, kin, kout, vin, vout,
                            spine, prefix16, totals, p);
 }
 

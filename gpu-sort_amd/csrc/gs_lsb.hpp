@@ -45,6 +45,17 @@ __device__ __forceinline__ uint32_t tile_of_item(uint32_t i, uint32_t full_tiles
     return base + (r % MI355X_XCDS) * (LSB_RESIDENT / MI355X_XCDS) + r / MI355X_XCDS;
 }
 
+// Upsweep block i -> chunk: inside every group of LSB_UPSWEEP_GROUP blocks the blocks of one XCD take consecutive
+// chunks (their totals are neighbours in the spine rows).  Speed only.
+constexpr uint32_t LSB_UPSWEEP_GROUP = 256;
+__device__ __forceinline__ uint32_t chunk_of_block(uint32_t b, uint32_t grid)
+{
+    const uint32_t base = (b / LSB_UPSWEEP_GROUP) * LSB_UPSWEEP_GROUP;
+    if (base + LSB_UPSWEEP_GROUP > grid) return b;   // ragged last group: identity
+    const uint32_t r = b - base;
+    return base + (r % MI355X_XCDS) * (LSB_UPSWEEP_GROUP / MI355X_XCDS) + r / MI355X_XCDS;
+}
+
 // Pipelined pass (gs_lsb.hip, lsb_pipe_pass_kernel): the three steps of a pass run inside ONE launch, the upsweep a
 // bounded distance ahead of the downsweep, so that the downsweep's re-read of the keys is served by the Infinity Cache.
 struct PipeParams {

@@ -287,7 +287,10 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int 
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
     uint32_t *my = lh[w][lane & (SUB - 1)];
     constexpr int BATCH = 32;
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    for (uint32_t c0 = blockIdx.x; c0 < nchunks; c0 += gridDim.x) {
+        // the blocks of one XCD take consecutive chunks: neighbours in the spine rows meet in one L2 (see lsb_upsweep_kernel;
+        // a block that loops strides by MSB_MAX_GRID, a multiple of 8, so it stays on its residue class)
+        const uint32_t c = chunk_of_block(c0, nchunks);
         for (int i = lane; i < SUB * (RADIX + 1); i += WAVE) (&lh[w][0][0])[i] = 0;
         const uint32_t g = c * MSB_WAVES + (uint32_t)w;
         if (g < ntiles) {
