@@ -45,8 +45,12 @@ constexpr uint32_t MSB_MERGE = 3000;               // merge adjacent sub-buckets
 constexpr uint32_t MSB_MAX_GRID = 16384;           // blocks per launch; kernels stride over longer lists
 // local-sort classes: threads x keys per thread = capacity 2048, 4608, 9216, 17408.  The two big
 // classes run 1024 threads so that two workgroups per CU give 32 waves.
-__host__ __device__ constexpr int msb_class_threads(int c) { return c < 2 ? 512 : 1024; }
-__host__ __device__ constexpr int msb_class_kpt(int c) { return c == 0 ? 4 : c == 1 ? 9 : c == 2 ? 9 : 17; }
+#ifndef GS_LS3_THREADS
+#define GS_LS3_THREADS 1024
+#define GS_LS3_KPT 17
+#endif
+__host__ __device__ constexpr int msb_class_threads(int c) { return c < 2 ? 512 : c == 2 ? 1024 : GS_LS3_THREADS; }
+__host__ __device__ constexpr int msb_class_kpt(int c) { return c == 0 ? 4 : c == 1 ? 9 : c == 2 ? 9 : GS_LS3_KPT; }
 __host__ __device__ constexpr uint32_t msb_class_cap(int c) { return (uint32_t)(msb_class_kpt(c) * msb_class_threads(c)); }
 // tiles of a range of x keys; x + MSB_TILE - 1 would wrap for ranges within one tile of 2^32
 __host__ __device__ constexpr uint32_t msb_tiles_of(uint32_t x) { return x / (uint32_t)MSB_TILE + (x % (uint32_t)MSB_TILE ? 1u : 0u); }
@@ -926,7 +930,13 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                 }
                 if (__builtin_amdgcn_ballot_w64(__popcll(same) >= 3) != 0ull) mine = false;
             }
-            if (mine) { out = c; break; }
+            if (mine) {   // wave-uniform: keep the record in scalar registers (the 64-VGPR budget of the big classes is tight)
+                out.offset = __builtin_amdgcn_readfirstlane(c.offset);
+                out.size = __builtin_amdgcn_readfirstlane(c.size);
+                out.sort_bits = __builtin_amdgcn_readfirstlane(c.sort_bits);
+                out.pad = __builtin_amdgcn_readfirstlane(c.pad);
+                break;
+            }
             if (MODE == LS_ONEPASS && tid == 0) { ws.tasks[cls][t].pad = c.pad | LS_FLAG; ws.level[L].flagged = 1u; }
         }
         return t;
@@ -950,6 +960,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
         }
     };
     request(T);
+    [[maybe_unused]] bool zeroed = false;   // LS_ONEPASS: the staging buffer holds zeros (cleared by the store phase)
     for (;;) {
         MsbTask Tn = T;
         const uint32_t tn = advance(ti + gridDim.x, Tn);
@@ -973,11 +984,22 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
         bool done = false;
         if constexpr (MODE == LS_ONEPASS) {
             const uint32_t nwords = (1u << B) >> 2, maskB = (1u << B) - 1u;
-            for (uint32_t j = tid; j < nwords; j += THREADS) sm.hist[j] = 0;
-            __syncthreads();
+            // the counters are zero here: the block's first task zeroes them below, every later one finds them zeroed by
+            // the store phase of the task before (each thread clears the slots it has just read: no barrier, no extra loop)
+            if (!zeroed) {
+                for (uint32_t j = tid; j < nwords; j += THREADS) sm.hist[j] = 0;
+                __syncthreads();
+            }
+            zeroed = false;
             uint32_t overflow = 0;
             {
                 const uint32_t wbase = fresh(wbase0);
+                // a bin shared by a whole wave (64 equal keys side by side) would queue 64 adds on one counter: looked for on
+                // two of the wave's rounds instead of on each (Zipf tasks with such runs mostly fail the 64-key look above)
+                const uint32_t ba = key[0] & maskB, bb = key[KPT / 2] & maskB;
+                const bool hot = __builtin_amdgcn_ballot_w64(ba == __builtin_amdgcn_readfirstlane(ba)) == __builtin_amdgcn_ballot_w64(true) ||
+                                 __builtin_amdgcn_ballot_w64(bb == __builtin_amdgcn_readfirstlane(bb)) == __builtin_amdgcn_ballot_w64(true);
+                if (hot) {
 #pragma unroll
                 for (int i = 0; i < KPT; ++i) {
                     pos[i] = 0;
@@ -999,6 +1021,18 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                         }
                         pos[i] = r;
                     }
+                }
+                } else {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    pos[i] = 0;
+                    if (wbase + i * WAVE < T.size) {
+                        const uint32_t bin = key[i] & maskB, sh = (bin & 3u) * 8u;
+                        const uint32_t r = (atomicAdd(&sm.hist[bin >> 2], 1u << sh) >> sh) & 255u;
+                        overflow |= (r >= 255u) ? 1u : 0u;
+                        pos[i] = r;
+                    }
+                }
                 }
             }
             if (!__syncthreads_or((int)overflow)) {
@@ -1255,6 +1289,12 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
             const uint32_t t0 = fresh((uint32_t)tid);
 #pragma unroll
             for (int i = 0; i < KPT; ++i) pos[i] = sm.stage[t0 + i * THREADS];   // `pos` is free: batch the reads
+            if constexpr (MODE == LS_ONEPASS && !HAS_VALUES) {
+                // the slots become the next task's byte counters: each thread clears what it has just read
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) sm.stage[t0 + i * THREADS] = 0;
+                zeroed = true;
+            }
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t j = t0 + i * THREADS;
