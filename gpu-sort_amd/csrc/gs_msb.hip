@@ -884,7 +884,9 @@ struct LocalSmem {
 // LS_FLAGGED per class: two lean kernels instead of one that holds both plans (and spills at 64 VGPRs).
 enum { LS_ALL = 0, LS_ONEPASS = 1, LS_FLAGGED = 2 };
 constexpr uint32_t LS_FLAG = 0x80000000u;
-template <int THREADS, int KPT, bool HAS_VALUES, bool STABLE = false, int MODE = LS_ALL>
+// PLAIN: no key transform on the way in or out (u32 ascending): instantiated for the one-pass kernels, where it is 9 of ~30
+// vector instructions per key.
+template <int THREADS, int KPT, bool HAS_VALUES, bool STABLE = false, int MODE = LS_ALL, bool PLAIN = false>
 __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 9)) ? 8 : 4) void msb_local_sort_kernel(
     MsbWs ws, int L, int cls, const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k, const uint32_t *__restrict__ src_v,
     uint32_t *__restrict__ dst_v, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out)
@@ -970,7 +972,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t idx = wbase + i * WAVE;
-                const uint32_t k = twiddle_in(key[i], f32_in, xor_in);
+                const uint32_t k = PLAIN ? key[i] : twiddle_in(key[i], f32_in, xor_in);
                 key[i] = (idx < T.size) ? k : 0xffffffffu;   // padding sorts last (keys are in twiddled form)
             }
         }
@@ -983,7 +985,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
         // (heavy duplicates) abandons the attempt: the keys are untouched and the general plan below runs.
         bool done = false;
         if constexpr (MODE == LS_ONEPASS) {
-            const uint32_t nwords = (1u << B) >> 2, maskB = (1u << B) - 1u;
+            const uint32_t nwords = (1u << B) >> 2, maskB = (1u << B) - 1u, wmask = maskB & ~3u;   // wmask: byte offset of a bin's word
             // the counters are zero here: the block's first task zeroes them below, every later one finds them zeroed by
             // the store phase of the task before (each thread clears the slots it has just read: no barrier, no extra loop)
             if (!zeroed) {
@@ -1023,28 +1025,26 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                     }
                 }
                 } else {
+                    // no guards: a pad (all ones) adds 0 to the last word; what it reads back is a real counter, so the
+                    // overflow test below stays exact.  8 vector instructions per key.
+                    uint32_t rmax = 0;
 #pragma unroll
-                for (int i = 0; i < KPT; ++i) {
-                    pos[i] = 0;
-                    if (wbase + i * WAVE < T.size) {
-                        const uint32_t bin = key[i] & maskB, sh = (bin & 3u) * 8u;
-                        const uint32_t r = (atomicAdd(&sm.hist[bin >> 2], 1u << sh) >> sh) & 255u;
-                        overflow |= (r >= 255u) ? 1u : 0u;
-                        pos[i] = r;
+                    for (int i = 0; i < KPT; ++i) {
+                        const uint32_t sh = (key[i] & 3u) << 3;
+                        const uint32_t inc = (wbase + i * WAVE < T.size) ? (1u << sh) : 0u;
+                        const uint32_t old = atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(sm.hist) + (key[i] & wmask)), inc);
+                        pos[i] = __builtin_amdgcn_ubfe(old, sh, 8u);
+                        rmax = pos[i] > rmax ? pos[i] : rmax;
                     }
-                }
+                    overflow = (rmax >= 255u) ? 1u : 0u;
                 }
             }
             if (!__syncthreads_or((int)overflow)) {
-                {   // offset inside the counter word: keys of the lower bins of the same word
-                    const uint32_t wbase = fresh(wbase0);
+                {   // offset inside the counter word: keys of the lower bins of the same word (pads compute garbage they never use)
 #pragma unroll
                     for (int i = 0; i < KPT; ++i) {
-                        if (wbase + i * WAVE < T.size) {
-                            const uint32_t bin = key[i] & maskB;
-                            const uint32_t wd = sm.hist[bin >> 2];
-                            pos[i] += __builtin_amdgcn_sad_u8(wd & ((1u << ((bin & 3u) * 8u)) - 1u), 0u, 0u);
-                        }
+                        const uint32_t wd = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sm.hist) + (key[i] & wmask));
+                        pos[i] = __builtin_amdgcn_sad_u8(__builtin_amdgcn_ubfe(wd, 0u, (key[i] & 3u) << 3), 0u, pos[i]);
                     }
                 }
 #pragma unroll
@@ -1084,18 +1084,19 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                 }
                 __syncthreads();
 #pragma unroll
-                for (int i = 0; i < KPT; ++i) pos[i] += sm.hist[(key[i] & maskB) >> 2];
+                for (int i = 0; i < KPT; ++i) pos[i] += *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sm.hist) + (key[i] & wmask));
 #pragma unroll
                 for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]));
                 __syncthreads();                          // the counters are dead: the buffer takes the keys
                 {
+                    // no guards: a pad goes to its own load slot, which lies behind the real keys
                     const uint32_t wbase = fresh(wbase0);
 #pragma unroll
                     for (int i = 0; i < KPT; ++i) {
-                        if (wbase + i * WAVE < T.size) {
-                            if (HAS_VALUES) reinterpret_cast<uint2 *>(sm.stage)[pos[i]] = make_uint2(key[i], val[i]);
-                            else sm.stage[pos[i]] = key[i];
-                        }
+                        const uint32_t idx = wbase + i * WAVE;
+                        const uint32_t at = idx < T.size ? pos[i] : idx;
+                        if (HAS_VALUES) reinterpret_cast<uint2 *>(sm.stage)[at] = make_uint2(key[i], val[i]);
+                        else sm.stage[at] = key[i];
                     }
                 }
                 __syncthreads();
@@ -1282,7 +1283,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
             for (uint32_t j = tid; j < T.size; j += THREADS) {
                 const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[j];
                 // whole lines of final output, written once: streaming stores (+0.3...0.7 % on the whole sort)
-                __builtin_nontemporal_store(twiddle_out(kv.x, f32_out, xor_out), &qk[j]);
+                __builtin_nontemporal_store(PLAIN ? kv.x : twiddle_out(kv.x, f32_out, xor_out), &qk[j]);
                 __builtin_nontemporal_store(kv.y, &qv[j]);
             }
         } else {
@@ -1298,7 +1299,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
                 const uint32_t j = t0 + i * THREADS;
-                if (j < T.size) __builtin_nontemporal_store(twiddle_out(pos[i], f32_out, xor_out), reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(qk) + j * 4u));
+                if (j < T.size) __builtin_nontemporal_store(PLAIN ? pos[i] : twiddle_out(pos[i], f32_out, xor_out), reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(qk) + j * 4u));
             }
         }
         }   // done
@@ -1376,15 +1377,17 @@ static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uin
         }
         return (uint32_t)(b < MSB_MAX_GRID ? (b ? b : 1) : MSB_MAX_GRID);
     };
-#define GS_LS1(C, HV, M) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV, STABLE, M>), dim3(grid_of(C)), \
-                                            dim3(msb_class_threads(C)), 0, s, ws, L, C, sk, dk, sv, dv, f32_in, xor_in, f32_out, xor_out)
+#define GS_LS1P(C, HV, M, P) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV, STABLE, M, P>), dim3(grid_of(C)), \
+                                               dim3(msb_class_threads(C)), 0, s, ws, L, C, sk, dk, sv, dv, f32_in, xor_in, f32_out, xor_out)
+#define GS_LS1(C, HV, M) GS_LS1P(C, HV, M, false)
+    const bool plain = !f32_in && !xor_in && !f32_out && !xor_out;
     // unstable sort: the one-pass kernel takes what it can and flags the rest for the general one
 #define GS_LS(C, HV)                                                                                                  \
     do {                                                                                                              \
         if constexpr (STABLE) { GS_LS1(C, HV, LS_ALL); }                                                              \
         else if (!onepass_possible(min_bits, local_b1((int)msb_class_cap(C)), local_b1((int)msb_class_cap(C) * (HV ? 2 : 1)) + 2)) \
             { GS_LS1(C, HV, LS_ALL); }                                                                                \
-        else { GS_LS1(C, HV, LS_ONEPASS); GS_LS1(C, HV, LS_FLAGGED); }                                                \
+        else { if (plain) GS_LS1P(C, HV, LS_ONEPASS, true); else GS_LS1(C, HV, LS_ONEPASS); GS_LS1(C, HV, LS_FLAGGED); } \
     } while (0)
     GS_LS(0, HAS_VALUES);
     GS_LS(1, HAS_VALUES);
@@ -1392,6 +1395,7 @@ static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uin
     if (!HAS_VALUES || GS_PAIR_CLASSES > 3) GS_LS(3, HAS_VALUES);
 #undef GS_LS
 #undef GS_LS1
+#undef GS_LS1P
 }
 
 // Levels 1..3 (partition on bytes 2, 1, 0 + the local sorts after each): keys travel between
