@@ -1375,7 +1375,10 @@ static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uin
             const uint64_t lim = num_items / msb_class_cap(c - 1) + RADIX;     // a class-c task holds > cap(c-1) keys
             if (lim < b) b = lim;
         }
-        return (uint32_t)(b < MSB_MAX_GRID ? (b ? b : 1) : MSB_MAX_GRID);
+#ifndef MSB_LS_MAX_GRID
+#define MSB_LS_MAX_GRID MSB_MAX_GRID
+#endif
+        return (uint32_t)(b < MSB_LS_MAX_GRID ? (b ? b : 1) : MSB_LS_MAX_GRID);
     };
 #define GS_LS1P(C, HV, M, P) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV, STABLE, M, P>), dim3(grid_of(C)), \
                                                dim3(msb_class_threads(C)), 0, s, ws, L, C, sk, dk, sv, dv, f32_in, xor_in, f32_out, xor_out)
