@@ -337,12 +337,10 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int 
                         if (j + u * WAVE + lane < T.valid) count(v[u]);
                 }
             }
-            if (PIVOT && examine) {
-                if (lane == 0) {
-                    if (n_eq) atomicAdd(&ws.pivots[T.bucket].eq, n_eq);
-                    if (n_less) atomicAdd(&ws.pivots[T.bucket].less, n_less);
-                }
-            }
+            // the tile's tallies go into its own record (both <= 8192); the classification sums them per bucket.  (Two global
+            // atomics per tile on the bucket's counters made the tiles of one hot bucket queue on two addresses: 2^28 keys, half
+            // of them one value: 1.14 ms for the level's histograms instead of 0.46.)
+            if (PIVOT && examine && lane == 0) ws.tiles[g].pad = n_eq | (n_less << 16);
         }
         __syncthreads();
         if (tid < RADIX) {
@@ -405,7 +403,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t s_cnt[RADIX], s_abs[RADIX], s_task[RADIX], s_nsub[RADIX];
     __shared__ uint8_t s_large[RADIX];
-    __shared__ uint32_t s_tot[2], s_ccnt[MSB_NCLASS], s_cbase[MSB_NCLASS], s_ksum[2];
+    __shared__ uint32_t s_tot[2], s_ccnt[MSB_NCLASS], s_cbase[MSB_NCLASS], s_ksum[2], s_piv[2];
     __shared__ unsigned long long s_base64;
     uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
     if (nb > ws.max_buckets) nb = ws.max_buckets;              // never (see MsbWs)
@@ -415,10 +413,25 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const MsbBucket B = ws.buckets[L & 1][b];
         if (PIVOT) {
-            const MsbPivot P = ws.pivots[b];
+            MsbPivot P = ws.pivots[b];
+            if (P.examine) {   // uniform for the block: sum the tallies the upsweep left in the bucket's tile records
+                if (d < 2) s_piv[d] = 0;
+                __syncthreads();
+                uint32_t eq = 0, less = 0;
+                for (uint32_t t = (uint32_t)d; t < B.tiles; t += RADIX) {
+                    const uint32_t w = ws.tiles[B.tile_start + t].pad;
+                    eq += w & 0xffffu; less += w >> 16;
+                }
+                eq = wave_inclusive_scan(eq); less = wave_inclusive_scan(less);
+                if (lane_id() == 63) { atomicAdd(&s_piv[0], eq); atomicAdd(&s_piv[1], less); }
+                __syncthreads();
+                P.eq = s_piv[0]; P.less = s_piv[1];
+                __syncthreads();
+            }
             const uint32_t greater = B.size - P.eq - P.less;
             if (P.examine && P.eq >= B.size - P.eq && P.less <= cap_max && greater <= cap_max) {   // uniform for the block
                 if (d == 0) {
+                    ws.pivots[b].eq = P.eq; ws.pivots[b].less = P.less;
                     ws.pivots[b].flag = 1u;
                     atomicAdd(&ws.level[L].pivot_buckets, 1u);
                     atomicAdd(&ws.level[L].pivot_keys, (unsigned long long)B.size);
