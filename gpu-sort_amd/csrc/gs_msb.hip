@@ -70,12 +70,17 @@ struct MsbLevel {
     uint32_t task_count[MSB_NCLASS];     // local-sort tasks emitted by this level's classification
     uint32_t flagged;                    // != 0: the one-pass local sort left tasks to the general kernel (a plain store:
                                          // thousands of atomics on one word would cost a millisecond)
-    uint32_t pivot_buckets;              // buckets of this level finished by the heavy-hitter path (see MsbPivot)
-    unsigned long long pivot_keys;       // keys in them
-    unsigned long long keys;             // keys in this level's buckets                 } census only
-    unsigned long long task_keys;        // keys in the tasks this level's classification emitted   } (gs_msb_census)
-    unsigned long long pad;
+    uint32_t unused0;
+    unsigned long long unused1;
+    unsigned long long keys;             // level 0: the array's size (census)
+    unsigned long long unused2;
+    uint32_t census_blocks, pad;         // slots of MsbWs::census this level's classification wrote
 };
+// Census (gs_msb_census: what bench.py prices the MSB sort's algorithmic bytes with).  Every classification block sums what
+// its buckets pass on and leaves ONE record; the reader adds them up.  (Three or four global atomics per bucket on the
+// level's counters were half of the classification's time once a level had thousands of buckets: Zipf 2^30, 0.46 -> 0.25 ms.)
+struct MsbCensusSlot { unsigned long long next_keys, task_keys, pivot_keys, pivot_buckets; };
+constexpr uint32_t MSB_CLASSIFY_GRID = 4096;   // classification blocks per launch at most = census slots per level
 // Heavy hitters (skewed inputs: BASELINE configs[3], Zipf).  A bucket in which ONE key value holds at least half of the
 // keys -- and the keys below and above it each fit a local sort -- is finished where it stands instead of being
 // partitioned byte by byte down to the last level (the reference moves such keys at every remaining pass, only its
@@ -102,6 +107,7 @@ struct MsbWs {
     MsbLevel *level;                     // [5]
     MsbBucket *buckets[2];               // level L uses buckets[L & 1]
     MsbTile *tiles;                      // tile records of the current level
+    MsbCensusSlot *census;               // [MSB_LEVELS][MSB_CLASSIFY_GRID]
     uint32_t *cursors;                   // [max_buckets][256]: sub-bucket start - E(first tile, d)
     uint32_t *spine;                     // [256][stride]
     uint16_t *prefix16;                  // [max_tiles][256]
@@ -152,7 +158,8 @@ static size_t msb_ws_bytes(uint64_t n, bool has_values, uint32_t extra = 0, uint
     return align256(MSB_LEVELS * sizeof(MsbLevel)) + 2 * align256(mb * sizeof(MsbBucket)) + align256(ml * sizeof(MsbTile)) +
            align256(mb * RADIX * sizeof(uint32_t)) + align256((size_t)RADIX * (ml / MSB_WAVES) * sizeof(uint32_t)) +
            align256(ml * RADIX * sizeof(uint16_t)) + MSB_NCLASS * align256(mt * sizeof(MsbTask)) +
-           align256((size_t)extra * sizeof(MsbPiece)) + align256(mb * sizeof(MsbPivot));
+           align256((size_t)extra * sizeof(MsbPiece)) + align256(mb * sizeof(MsbPivot)) +
+           align256((size_t)MSB_LEVELS * MSB_CLASSIFY_GRID * sizeof(MsbCensusSlot));
 }
 static MsbWs msb_carve(void *temp, uint64_t n, bool has_values, uint32_t extra = 0, uint32_t extra_tasks = 0, uint32_t wide_cap = 0,
                        uint32_t key_bits = 32)
@@ -175,7 +182,8 @@ static MsbWs msb_carve(void *temp, uint64_t n, bool has_values, uint32_t extra =
     ws.prefix16 = (uint16_t *)c; c += align256((size_t)ws.max_tiles * RADIX * sizeof(uint16_t));
     for (int i = 0; i < MSB_NCLASS; ++i) { ws.tasks[i] = (MsbTask *)c; c += align256((size_t)ws.max_tasks * sizeof(MsbTask)); }
     ws.pieces = (MsbPiece *)c; c += align256((size_t)extra * sizeof(MsbPiece));
-    ws.pivots = (MsbPivot *)c;
+    ws.pivots = (MsbPivot *)c; c += align256((size_t)ws.max_buckets * sizeof(MsbPivot));
+    ws.census = (MsbCensusSlot *)c;
     return ws;
 }
 
@@ -408,6 +416,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
     uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
     if (nb > ws.max_buckets) nb = ws.max_buckets;              // never (see MsbWs)
     const int d = threadIdx.x;
+    MsbCensusSlot acc{0ull, 0ull, 0ull, 0ull};                   // thread 0's running census of this block's buckets
     const uint32_t cap_max = nclass > 0 ? ws.caps[nclass - 1] : 0xffffffffu;   // nclass 0: cursors only (LAST)
     const uint32_t rb = ws.key_bits - 8u - 8u * (uint32_t)L;     // bits below this level's byte
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
@@ -433,9 +442,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
                 if (d == 0) {
                     ws.pivots[b].eq = P.eq; ws.pivots[b].less = P.less;
                     ws.pivots[b].flag = 1u;
-                    atomicAdd(&ws.level[L].pivot_buckets, 1u);
-                    atomicAdd(&ws.level[L].pivot_keys, (unsigned long long)B.size);
-                    atomicAdd(&ws.level[L].task_keys, (unsigned long long)(P.less + greater));
+                    acc.pivot_buckets += 1ull; acc.pivot_keys += B.size; acc.task_keys += P.less + greater;
                     // the strangers share the bucket's upper bytes only: their tasks sort this level's byte too
                     const uint32_t offs[2] = {B.offset, B.offset + P.less + P.eq}, sizes[2] = {P.less, greater};
                     for (int q = 0; q < 2; ++q) {
@@ -510,8 +517,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
             if (s_tot[0]) old = atomicAdd(&ws.level[L + 1].packed, ((unsigned long long)s_tot[0] << 32) | s_tot[1]);
             s_base64 = old;
             // census: keys passed on to the next level / handed to local sorts
-            if (s_ksum[0]) atomicAdd(&ws.level[L + 1].keys, (unsigned long long)s_ksum[0]);
-            if (s_ksum[1]) atomicAdd(&ws.level[L].task_keys, (unsigned long long)s_ksum[1]);
+            acc.next_keys += s_ksum[0]; acc.task_keys += s_ksum[1];
         }
         if (d < MSB_NCLASS) {
             const uint32_t k = s_ccnt[d];
@@ -526,6 +532,10 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
             if (s_cbase[cls] + task_local < ws.max_tasks)
                 ws.tasks[cls][s_cbase[cls] + task_local] = MsbTask{abs, tsize, rb + (s_nsub[d] > 1 ? 8u : 0u), 0u};
         }
+    }
+    if (d == 0 && blockIdx.x < MSB_CLASSIFY_GRID) {
+        ws.census[(size_t)L * MSB_CLASSIFY_GRID + blockIdx.x] = acc;
+        if (blockIdx.x == 0) ws.level[L].census_blocks = gridDim.x < MSB_CLASSIFY_GRID ? gridDim.x : MSB_CLASSIFY_GRID;
     }
 }
 
@@ -2051,17 +2061,29 @@ int gs_msb_census(void *d_temp, uint64_t num_items, int has_values, gs_msb_level
     if (!d_temp || !out || num_items >= (1ull << 32)) return hipErrorInvalidValue;
     const MsbWs ws = msb_carve((char *)d_temp + align256(lsb_temp_bytes(num_items)), num_items, has_values != 0);
     MsbLevel lv[4];
+    std::vector<MsbCensusSlot> slots((size_t)4 * MSB_CLASSIFY_GRID);
     hipError_t e = hipMemcpyAsync(lv, ws.level, sizeof(lv), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(slots.data(), ws.census, slots.size() * sizeof(MsbCensusSlot), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
+    MsbCensusSlot sum[4] = {};
+    for (int L = 0; L < 4; ++L) {
+        const uint32_t nbk = lv[L].census_blocks < MSB_CLASSIFY_GRID ? lv[L].census_blocks : MSB_CLASSIFY_GRID;
+        for (uint32_t i = 0; i < nbk; ++i) {
+            const MsbCensusSlot &q = slots[(size_t)L * MSB_CLASSIFY_GRID + i];
+            sum[L].next_keys += q.next_keys; sum[L].task_keys += q.task_keys;
+            sum[L].pivot_keys += q.pivot_keys; sum[L].pivot_buckets += q.pivot_buckets;
+        }
+    }
     for (int L = 0; L < 4; ++L) {
         gs_msb_level_census c{};
         c.buckets = lv[L].packed >> 32;
         c.tiles = (uint32_t)lv[L].packed;
-        c.keys = lv[L].keys;
-        c.pivot_buckets = lv[L].pivot_buckets;
-        c.pivot_keys = lv[L].pivot_keys;
-        c.task_keys = lv[L].task_keys;
+        c.keys = L == 0 ? lv[0].keys : sum[L - 1].next_keys;
+        c.pivot_buckets = (uint32_t)sum[L].pivot_buckets;
+        c.pivot_keys = sum[L].pivot_keys;
+        c.task_keys = sum[L].task_keys;
         for (int q = 0; q < MSB_NCLASS; ++q) c.tasks[q] = lv[L].task_count[q];
         c.flagged = lv[L].flagged;
         out[L] = c;
