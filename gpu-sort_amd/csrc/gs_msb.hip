@@ -49,8 +49,20 @@ constexpr uint32_t MSB_MAX_GRID = 16384;           // blocks per launch; kernels
 #define GS_LS3_THREADS 1024
 #define GS_LS3_KPT 17
 #endif
-__host__ __device__ constexpr int msb_class_threads(int c) { return c < 2 ? 512 : c == 2 ? 1024 : GS_LS3_THREADS; }
-__host__ __device__ constexpr int msb_class_kpt(int c) { return c == 0 ? 4 : c == 1 ? 9 : c == 2 ? 9 : GS_LS3_KPT; }
+#ifndef GS_LS2_THREADS
+#define GS_LS2_THREADS 512
+#define GS_LS2_KPT 18
+#endif
+#ifndef GS_LS1_THREADS
+#define GS_LS1_THREADS 512
+#define GS_LS1_KPT 9
+#endif
+#ifndef GS_LS0_THREADS
+#define GS_LS0_THREADS 512
+#define GS_LS0_KPT 4
+#endif
+__host__ __device__ constexpr int msb_class_threads(int c) { return c == 0 ? GS_LS0_THREADS : c == 1 ? GS_LS1_THREADS : c == 2 ? GS_LS2_THREADS : GS_LS3_THREADS; }
+__host__ __device__ constexpr int msb_class_kpt(int c) { return c == 0 ? GS_LS0_KPT : c == 1 ? GS_LS1_KPT : c == 2 ? GS_LS2_KPT : GS_LS3_KPT; }
 __host__ __device__ constexpr uint32_t msb_class_cap(int c) { return (uint32_t)(msb_class_kpt(c) * msb_class_threads(c)); }
 // tiles of a range of x keys; x + MSB_TILE - 1 would wrap for ranges within one tile of 2^32
 __host__ __device__ constexpr uint32_t msb_tiles_of(uint32_t x) { return x / (uint32_t)MSB_TILE + (x % (uint32_t)MSB_TILE ? 1u : 0u); }
@@ -910,7 +922,10 @@ constexpr uint32_t LS_FLAG = 0x80000000u;
 // PLAIN: no key transform on the way in or out (u32 ascending): instantiated for the one-pass kernels, where it is 9 of ~30
 // vector instructions per key.
 template <int THREADS, int KPT, bool HAS_VALUES, bool STABLE = false, int MODE = LS_ALL, bool PLAIN = false>
-__global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 9)) ? 8 : 4) void msb_local_sort_kernel(
+#ifndef GS_LS_WPE_512x18
+#define GS_LS_WPE_512x18 4
+#endif
+__global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 9)) ? 8 : (THREADS == 512 && KPT == 18 && !HAS_VALUES) ? GS_LS_WPE_512x18 : 4) void msb_local_sort_kernel(
     MsbWs ws, int L, int cls, const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k, const uint32_t *__restrict__ src_v,
     uint32_t *__restrict__ dst_v, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out)
 {
