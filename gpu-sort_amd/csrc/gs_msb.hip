@@ -417,6 +417,18 @@ __global__ __launch_bounds__(1024) void msb_scan_kernel(MsbWs ws, int L)
 // `counts0`: level 0 of the sort reads the LSB pass's digit totals instead
 // (and needs no cursors: the LSB downsweep does that scatter).
 // PIVOT: a bucket dominated by one key value is finished by the heavy-hitter path instead (see MsbPivot).
+// v_writelane_b32: lane `lane` (wave-uniform) of `v` takes the wave-uniform `value`
+__device__ __forceinline__ void write_lane(uint32_t &v, uint32_t value, uint32_t lane)
+{
+    const uint32_t sv = __builtin_amdgcn_readfirstlane(value), sl = __builtin_amdgcn_readfirstlane(lane);
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(sv), "s"(sl) : "m0");   // one SGPR operand + m0 (constant bus)
+}
+#ifdef GS_EXP_CLS
+__device__ unsigned long long gs_cls_stamp[16 * 8];   // experiment: s_memrealtime stamps of block 0, per level
+#define CLS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) gs_cls_stamp[L * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CLS_STAMP(k) do { } while (0)
+#endif
 template <bool LAST, bool PIVOT = false>
 __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, const uint32_t *__restrict__ counts0, int nclass)
 {
@@ -429,6 +441,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
     if (nb > ws.max_buckets) nb = ws.max_buckets;              // never (see MsbWs)
     const int d = threadIdx.x;
     MsbCensusSlot acc{0ull, 0ull, 0ull, 0ull};                   // thread 0's running census of this block's buckets
+    CLS_STAMP(0);
     const uint32_t cap_max = nclass > 0 ? ws.caps[nclass - 1] : 0xffffffffu;   // nclass 0: cursors only (LAST)
     const uint32_t rb = ws.key_bits - 8u - 8u * (uint32_t)L;     // bits below this level's byte
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
@@ -477,35 +490,69 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
             e0 = srow[g0 / MSB_WAVES] + ws.prefix16[(size_t)g0 * RADIX + d];
             c = srow[g1 / MSB_WAVES] + ws.prefix16[(size_t)g1 * RADIX + d] - e0;
         }
+        CLS_STAMP(1);
         const uint32_t ex = block_exclusive_scan_256(c, scratch, nullptr);
+        CLS_STAMP(2);
         const uint32_t abs = B.offset + ex;
         if (!counts0) ws.cursors[(size_t)b * RADIX + d] = abs - e0;
         if (LAST) continue;
         s_cnt[d] = c; s_abs[d] = abs; s_task[d] = 0; s_nsub[d] = 0; s_large[d] = 0;
         if (d < MSB_NCLASS) s_ccnt[d] = 0;
         if (d < 2) s_ksum[d] = 0;
-        __syncthreads();
-        if (d == 0) {
+        // no sub-bucket below the merge threshold: nothing can merge, every thread settles its own digit (the walk below costs
+        // 25-40 us per block, scalar code or not: a single wave doing serial work)
+        const int any_small = __syncthreads_or(c != 0u && c < (uint32_t)MSB_MERGE);
+        CLS_STAMP(3);
+        if (!any_small) {
+            const bool lg = c > cap_max;
+            s_large[d] = lg ? 1 : 0;
+            s_task[d] = (c != 0u && !lg) ? c : 0u;
+            s_nsub[d] = (c != 0u && !lg) ? 1u : 0u;
+        } else if (wave_id() == 0) {
+            // the greedy merge walks the 256 counts in order.  Wave 0 holds them in registers (4 per lane), reads them with
+            // v_readlane and keeps its verdicts in registers too (v_writelane), so the walk is scalar arithmetic with uniform
+            // control flow: 2 us instead of the 30 us one thread needed for 256 dependent LDS reads and guarded stores
+            const int ln = lane_id();
+            const uint32_t cv[4] = {s_cnt[ln], s_cnt[WAVE + ln], s_cnt[2 * WAVE + ln], s_cnt[3 * WAVE + ln]};
+            uint32_t tv[4] = {0u, 0u, 0u, 0u}, nv[4] = {0u, 0u, 0u, 0u}, lv = 0u;   // task size / sub-buckets at a run's first digit; bit s: digit 64 s + lane is large
             int run_start = -1;
             uint32_t run_sum = 0, run_nsub = 0;
-            for (int q = 0; q < RADIX; ++q) {
-                const uint32_t cq = s_cnt[q];
-                if (cq == 0) continue;
-                if (cq > cap_max) {
-                    if (run_start >= 0) { s_task[run_start] = run_sum; s_nsub[run_start] = run_nsub; run_start = -1; }
-                    s_large[q] = 1;
-                    continue;
-                }
-                if (run_start >= 0 && run_sum + cq < MSB_MERGE) {   // the reference's test (cuda_radix_sort.h:1084): sum AFTER adding
-                    run_sum += cq; ++run_nsub;
-                } else {
-                    if (run_start >= 0) { s_task[run_start] = run_sum; s_nsub[run_start] = run_nsub; }
-                    run_start = q; run_sum = cq; run_nsub = 1;
+            auto close_run = [&]() {
+                const int rs = run_start >> 6, rl = run_start & (WAVE - 1);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    if (rs == s4) {
+                        write_lane(tv[s4], run_sum, (uint32_t)rl);
+                        write_lane(nv[s4], run_nsub, (uint32_t)rl);
+                    }
+            };
+#pragma unroll
+            for (int seg = 0; seg < 4; ++seg) {
+#pragma unroll 1
+                for (int j = 0; j < WAVE; ++j) {
+                    const uint32_t cq = (uint32_t)__builtin_amdgcn_readlane((int)cv[seg], j);
+                    if (cq == 0) continue;
+                    if (cq > cap_max) {
+                        if (run_start >= 0) { close_run(); run_start = -1; }
+                        write_lane(lv, (uint32_t)__builtin_amdgcn_readlane((int)lv, j) | (1u << seg), (uint32_t)j);
+                        continue;
+                    }
+                    if (run_start >= 0 && run_sum + cq < MSB_MERGE) {   // the reference's test (cuda_radix_sort.h:1084): sum AFTER adding
+                        run_sum += cq; ++run_nsub;
+                    } else {
+                        if (run_start >= 0) close_run();
+                        run_start = seg * WAVE + j; run_sum = cq; run_nsub = 1;
+                    }
                 }
             }
-            if (run_start >= 0) { s_task[run_start] = run_sum; s_nsub[run_start] = run_nsub; }
+            if (run_start >= 0) close_run();
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                s_task[s4 * WAVE + ln] = tv[s4]; s_nsub[s4 * WAVE + ln] = nv[s4]; s_large[s4 * WAVE + ln] = (uint8_t)((lv >> s4) & 1u);
+            }
         }
         __syncthreads();
+        CLS_STAMP(4);
         // one global atomic per block and list (not per entry): count the block's new
         // buckets / tiles and its tasks per class in LDS, reserve the ranges, then fill
         uint32_t new_bucket = 0xffffffffu;
@@ -524,6 +571,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
             if (lane_id() == 0) { if (kl) atomicAdd(&s_ksum[0], kl); if (kt) atomicAdd(&s_ksum[1], kt); }
         }
         __syncthreads();
+        CLS_STAMP(5);
         if (d == 0) {
             unsigned long long old = 0;
             if (s_tot[0]) old = atomicAdd(&ws.level[L + 1].packed, ((unsigned long long)s_tot[0] << 32) | s_tot[1]);
@@ -536,6 +584,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
             s_cbase[d] = k ? atomicAdd(&ws.level[L].task_count[d], k) : 0u;
         }
         __syncthreads();
+        CLS_STAMP(6);
         if (is_large) {
             new_bucket = (uint32_t)(s_base64 >> 32) + bidx;
             if (new_bucket < ws.max_buckets)
@@ -545,7 +594,8 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
                 ws.tasks[cls][s_cbase[cls] + task_local] = MsbTask{abs, tsize, rb + (s_nsub[d] > 1 ? 8u : 0u), 0u};
         }
     }
-    if (d == 0 && blockIdx.x < MSB_CLASSIFY_GRID) {
+    CLS_STAMP(7);
+    if (!LAST && d == 0 && blockIdx.x < MSB_CLASSIFY_GRID) {   // (the last level passes nothing on: its records would be zeros)
         ws.census[(size_t)L * MSB_CLASSIFY_GRID + blockIdx.x] = acc;
         if (blockIdx.x == 0) ws.level[L].census_blocks = gridDim.x < MSB_CLASSIFY_GRID ? gridDim.x : MSB_CLASSIFY_GRID;
     }
@@ -2070,6 +2120,9 @@ int gs_msb_classify_upto(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint
                          stop_level, (flags & 1) == 0);
 }
 
+#ifdef GS_EXP_CLS
+int gs_exp_cls_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gs_cls_stamp), sizeof(unsigned long long) * 16 * 8); }
+#endif
 int gs_msb_census(void *d_temp, uint64_t num_items, int has_values, gs_msb_level_census out[4], void *stream)
 {
     GS_CLEAR_STALE_ERROR();
