@@ -417,12 +417,6 @@ __global__ __launch_bounds__(1024) void msb_scan_kernel(MsbWs ws, int L)
 // `counts0`: level 0 of the sort reads the LSB pass's digit totals instead
 // (and needs no cursors: the LSB downsweep does that scatter).
 // PIVOT: a bucket dominated by one key value is finished by the heavy-hitter path instead (see MsbPivot).
-// v_writelane_b32: lane `lane` (wave-uniform) of `v` takes the wave-uniform `value`
-__device__ __forceinline__ void write_lane(uint32_t &v, uint32_t value, uint32_t lane)
-{
-    const uint32_t sv = __builtin_amdgcn_readfirstlane(value), sl = __builtin_amdgcn_readfirstlane(lane);
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(sv), "s"(sl) : "m0");   // one SGPR operand + m0 (constant bus)
-}
 #ifdef GS_EXP_CLS
 __device__ unsigned long long gs_cls_stamp[16 * 8];   // experiment: s_memrealtime stamps of block 0, per level
 #define CLS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) gs_cls_stamp[L * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -436,6 +430,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
     __shared__ uint32_t s_cnt[RADIX], s_abs[RADIX], s_task[RADIX], s_nsub[RADIX];
     __shared__ uint8_t s_large[RADIX];
     __shared__ uint32_t s_tot[2], s_ccnt[MSB_NCLASS], s_cbase[MSB_NCLASS], s_ksum[2], s_piv[2];
+    __shared__ uint32_t s_p[RADIX], s_ln[RADIX], s_rank2idx[RADIX], s_mark[RADIX], s_jump[2][RADIX];   // the merge (see below)
     __shared__ unsigned long long s_base64;
     uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
     if (nb > ws.max_buckets) nb = ws.max_buckets;              // never (see MsbWs)
@@ -508,48 +503,52 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
             s_large[d] = lg ? 1 : 0;
             s_task[d] = (c != 0u && !lg) ? c : 0u;
             s_nsub[d] = (c != 0u && !lg) ? 1u : 0u;
-        } else if (wave_id() == 0) {
-            // the greedy merge walks the 256 counts in order.  Wave 0 holds them in registers (4 per lane), reads them with
-            // v_readlane and keeps its verdicts in registers too (v_writelane), so the walk is scalar arithmetic with uniform
-            // control flow: 2 us instead of the 30 us one thread needed for 256 dependent LDS reads and guarded stores
-            const int ln = lane_id();
-            const uint32_t cv[4] = {s_cnt[ln], s_cnt[WAVE + ln], s_cnt[2 * WAVE + ln], s_cnt[3 * WAVE + ln]};
-            uint32_t tv[4] = {0u, 0u, 0u, 0u}, nv[4] = {0u, 0u, 0u, 0u}, lv = 0u;   // task size / sub-buckets at a run's first digit; bit s: digit 64 s + lane is large
-            int run_start = -1;
-            uint32_t run_sum = 0, run_nsub = 0;
-            auto close_run = [&]() {
-                const int rs = run_start >> 6, rl = run_start & (WAVE - 1);
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-                    if (rs == s4) {
-                        write_lane(tv[s4], run_sum, (uint32_t)rl);
-                        write_lane(nv[s4], run_nsub, (uint32_t)rl);
-                    }
-            };
-#pragma unroll
-            for (int seg = 0; seg < 4; ++seg) {
-#pragma unroll 1
-                for (int j = 0; j < WAVE; ++j) {
-                    const uint32_t cq = (uint32_t)__builtin_amdgcn_readlane((int)cv[seg], j);
-                    if (cq == 0) continue;
-                    if (cq > cap_max) {
-                        if (run_start >= 0) { close_run(); run_start = -1; }
-                        write_lane(lv, (uint32_t)__builtin_amdgcn_readlane((int)lv, j) | (1u << seg), (uint32_t)j);
-                        continue;
-                    }
-                    if (run_start >= 0 && run_sum + cq < MSB_MERGE) {   // the reference's test (cuda_radix_sort.h:1084): sum AFTER adding
-                        run_sum += cq; ++run_nsub;
-                    } else {
-                        if (run_start >= 0) close_run();
-                        run_start = seg * WAVE + j; run_sum = cq; run_nsub = 1;
-                    }
+        } else {
+            // The reference's greedy merge (cuda_radix_sort.h:1084: a run of adjacent sub-buckets grows while its sum stays below
+            // MSB_MERGE; a sub-bucket too large for a local sort ends it) without walking the 256 counts one by one (25-40 us for
+            // a single wave): with P = prefix sums of the counts that may merge, a run that starts at i ends at the last j with
+            // P[j] - (P[i] - c_i) < MSB_MERGE and no large sub-bucket in (i, j] -- a binary search per digit; the run starts are
+            // the digits reachable from the first one through "next start after my run", marked by pointer doubling.
+            const bool lg = c > cap_max, normal = c != 0u && !lg;
+            const uint32_t p_ex = block_exclusive_scan_256(normal ? c : 0u, scratch, nullptr);
+            const uint32_t ln_ex = block_exclusive_scan_256((lg ? 0x10000u : 0u) | (normal ? 1u : 0u), scratch, &s_tot[0]);
+            const uint32_t p_in = p_ex + (normal ? c : 0u), ln_in = ln_ex + ((lg ? 0x10000u : 0u) | (normal ? 1u : 0u));
+            s_p[d] = p_in; s_ln[d] = ln_in; s_mark[d] = 0u;
+            if (normal) s_rank2idx[ln_ex & 0xffffu] = (uint32_t)d;      // the r-th digit that may merge
+            __syncthreads();
+            const uint32_t n_normal = s_tot[0] & 0xffffu;
+            uint32_t end = (uint32_t)d, jump = RADIX;
+            if (normal) {
+                // last j >= d with P[j] - p_ex < MSB_MERGE and as many large digits up to j as up to d (both hold, then fail)
+                uint32_t lo = (uint32_t)d, hi = RADIX - 1u;
+                const uint32_t larges = ln_in >> 16;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1u) >> 1;
+                    const bool ok = s_p[mid] - p_ex < (uint32_t)MSB_MERGE && (s_ln[mid] >> 16) == larges;
+                    if (ok) lo = mid; else hi = mid - 1u;
                 }
+                end = lo;                                               // == d when the digit alone reaches the threshold
+                const uint32_t r = s_ln[end] & 0xffffu;                 // digits that may merge up to `end` = rank of the next one
+                jump = r < n_normal ? s_rank2idx[r] : (uint32_t)RADIX;
             }
-            if (run_start >= 0) close_run();
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                s_task[s4 * WAVE + ln] = tv[s4]; s_nsub[s4 * WAVE + ln] = nv[s4]; s_large[s4 * WAVE + ln] = (uint8_t)((lv >> s4) & 1u);
+            s_jump[0][d] = jump;
+            if (d == 0 && n_normal) s_mark[s_rank2idx[0]] = 1u;
+            __syncthreads();
+#pragma unroll 1
+            for (int k = 0; k < 8; ++k) {                               // reach 2^k starts further per round
+                const uint32_t j = s_jump[k & 1][d];
+                if (j < (uint32_t)RADIX) {
+                    if (s_mark[d]) s_mark[j] = 1u;                      // marks only ever go from 0 to 1: no ordering needed
+                    s_jump[(k + 1) & 1][d] = s_jump[k & 1][j];
+                } else {
+                    s_jump[(k + 1) & 1][d] = (uint32_t)RADIX;
+                }
+                __syncthreads();
             }
+            const bool start = normal && s_mark[d] != 0u;
+            s_large[d] = lg ? 1 : 0;
+            s_task[d] = start ? s_p[end] - p_ex : 0u;
+            s_nsub[d] = start ? (s_ln[end] & 0xffffu) - (ln_ex & 0xffffu) : 0u;
         }
         __syncthreads();
         CLS_STAMP(4);
