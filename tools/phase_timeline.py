@@ -1,17 +1,20 @@
 """Experiment build only (-DGS_EXP_PHASES [-DGS_EXP_PERSIST=768]): timeline of the downsweep blocks of one pass —
 who ran where and when, how long each phase took, how evenly the CUs were served.
-GS_LIB_PATH=.../gsvariant_ph768.so python tools/phase_timeline.py [log2n]"""
+GS_LIB_PATH=.../gsvariant_ph768.so python tools/phase_timeline.py [log2n] [pairs]"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import gpu_sort_amd as gs
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+pairs = len(sys.argv) > 2 and sys.argv[2] == "pairs"
 n = 1 << logn
 dev = torch.device("cuda:0")
 raw = C.CDLL(gs.LIB_PATH)
 uni = gs.generate_uniform_keys(n, device=dev)
 a, b = torch.empty_like(uni), torch.empty_like(uni)
-nb = gs.lib.gs_lsb_temp_bytes(n, 0)
+nb = gs.lib.gs_lsb_temp_bytes(n, int(pairs))
+va = gs.generate_enumerated_values(n, device=dev) if pairs else None
+vb = torch.empty_like(uni) if pairs else None
 temp = torch.empty(nb, dtype=torch.uint8, device=dev)
 names = ["load issue", "load wait", "rank", "barrier1", "scan+bar2", "lds scatter", "barrier3", "store issue", "store drain"]
 tiles = n // 8192
@@ -21,7 +24,8 @@ for r in range(3):
     dk = gs.DoubleBuffer(a, b)
     torch.cuda.synchronize()
     with gs.KernelProfile() as prof:
-        gs.DeviceRadixSort.SortKeys(temp, nb, dk, n, 0, 8, key_type=gs.GS_KEY_U32)
+        if pairs: gs.DeviceRadixSort.SortPairs(temp, nb, dk, gs.DoubleBuffer(va, vb), n, 0, 8, key_type=gs.GS_KEY_U32)
+        else: gs.DeviceRadixSort.SortKeys(temp, nb, dk, n, 0, 8, key_type=gs.GS_KEY_U32)
         torch.cuda.synchronize()
 raw.gs_exp_phases(out.ctypes.data_as(C.c_void_p), tiles)
 m = out.reshape(tiles, 16).astype(np.int64)
