@@ -1499,6 +1499,58 @@ static inline bool msb_pivot_enabled()
     return on;
 }
 
+// ---- a look at the next level's size (levels 2 and 3).  Every level is launched with grids sized for the worst case and
+// its surplus blocks exit at once, but the launches of a level that turns out EMPTY still cost ~0.2 ms at 2^30 keys (131 K
+// blocks to dispatch for the scatter alone) -- 5 % of a uniform sort, 30 % at 2^24 keys.  So, when the stream is not being
+// captured into a graph: right after level L's classification a one-thread kernel copies level L+1's bucket / tile counts to
+// a pinned host word and an event is recorded; the scatter and the local sorts of level L are enqueued (milliseconds of
+// work), and only then the host waits for that event -- the device has long passed it -- and either skips the remaining
+// levels or launches level L+1 with exact grids.  The device never idles; under graph capture (no host waits allowed)
+// and with GS_MSB_PEEK=0 the worst-case grids are used as before.
+__global__ void msb_peek_kernel(MsbWs ws, int L, unsigned long long *mailbox)
+{
+    *mailbox = ws.level[L].packed;
+    __threadfence_system();
+}
+struct MsbPeek {
+    unsigned long long *host = nullptr, *dev = nullptr;
+    hipEvent_t ev = nullptr;
+    int device = -1;
+    bool armed = false;
+};
+static bool msb_peek_enabled()
+{
+    static const bool on = [] { const char *e = getenv("GS_MSB_PEEK"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// the calling thread's mailbox for the current device, or nullptr (then the caller keeps the worst-case grids)
+static MsbPeek *msb_peek_get(hipStream_t s)
+{
+    if (!msb_peek_enabled()) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    thread_local MsbPeek pk;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (pk.device != dev) {
+        if (pk.ev) { (void)hipEventDestroy(pk.ev); pk.ev = nullptr; }
+        if (pk.host) { (void)hipHostFree(pk.host); pk.host = nullptr; }
+        pk.device = -1;
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess ||
+            hipHostGetDevicePointer(&d, h, 0) != hipSuccess ||
+            hipEventCreateWithFlags(&pk.ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h) (void)hipHostFree(h);
+            pk.ev = nullptr;
+            return nullptr;
+        }
+        pk.host = (unsigned long long *)h; pk.dev = (unsigned long long *)d; pk.device = dev;
+    }
+    pk.armed = false;
+    return &pk;
+}
+
 // `stop_level` (test access, gs_msb_classify_upto): return right after that level's classification; `allow_pivot` = false
 // keeps the heavy-hitter path off whatever the environment says.
 static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint32_t npieces, uint32_t *const buf_k[2],
@@ -1509,7 +1561,21 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
     const uint32_t tiles_all = (uint32_t)((num_items + MSB_TILE - 1) / MSB_TILE);
     const uint32_t max_tasks_lvl = ws.max_tasks;
     uint32_t *d_keys = buf_k[0], *d_vals = buf_v[0];
+    MsbPeek *peek = stop_level == 99 ? msb_peek_get(s) : nullptr;
+    uint32_t known_b = 0, known_tiles = 0;     // level L's exact bucket / tile counts when the look succeeded
+    bool known = false;
     for (int L = 1; L <= 3; ++L) {
+        if (peek && peek->armed) {             // armed after level L-1's classification; the device is far past it by now
+            peek->armed = false;
+            if (hipEventSynchronize(peek->ev) == hipSuccess) {
+                const unsigned long long pkd = *(volatile unsigned long long *)peek->host;
+                known_b = (uint32_t)(pkd >> 32); known_tiles = (uint32_t)pkd; known = true;
+                if (known_b == 0) return;      // nothing left for this level or the ones below it
+            } else {
+                (void)hipGetLastError();
+                known = false;
+            }
+        }
         const int shift = 24 - 8 * L;
         const DigitSel dsel{shift, nullptr, 0, 0, 0u, 8, 0};
         uint32_t *sk = buf_k[L & 1], *dk = buf_k[(L + 1) & 1];
@@ -1519,8 +1585,13 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
         // already cover it)
         const bool pivot = allow_pivot && msb_pivot_enabled() && !pairs && !in_pieces && L <= 2;
         // buckets at level L: <= 256 at level 1, else bounded by size; tiles: n/T + one ragged tile per bucket (piece)
-        const uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
-        const uint32_t max_tiles = tiles_all + (in_pieces ? npieces : max_b);
+        uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
+        uint32_t max_tiles = tiles_all + (in_pieces ? npieces : max_b);
+        if (known && L >= 2) {                 // exact (never more than the bounds above)
+            if (known_b < max_b) max_b = known_b;
+            if (known_tiles < max_tiles) max_tiles = known_tiles;
+            known = false;
+        }
         // one tile per block, dispatched in order (blocks that own a long run of tiles march in
         // lockstep and lose a third of the bandwidth, like the LSB downsweep); surplus blocks exit
         const bool last = (L == 3);
@@ -1542,6 +1613,11 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
           else if (pivot) hipLaunchKernelGGL((msb_classify_kernel<false, true>), dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass);
           else hipLaunchKernelGGL((msb_classify_kernel<false, false>), dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass); }
         if (L == stop_level) return;
+        if (peek && !last) {
+            hipLaunchKernelGGL(msb_peek_kernel, dim3(1), dim3(1), 0, s, ws, L + 1, peek->dev);
+            peek->armed = hipEventRecord(peek->ev, s) == hipSuccess;
+            if (!peek->armed) (void)hipGetLastError();
+        }
         { KernelTimer kt(GS_K_MSB_PARTITION, s);
           const bool big = num_items > (1ull << 30);
           const uint32_t *svc = pairs ? (const uint32_t *)sv : (const uint32_t *)nullptr;
@@ -1553,8 +1629,10 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
 #undef GS_SC
         }
         if (!last) {
-            if (pairs) launch_local_sorts<true>(ws, L, max_tasks_lvl, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L, num_items);
-            else launch_local_sorts<false>(ws, L, max_tasks_lvl, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L, num_items);
+            // a bucket emits at most 256 tasks
+            const uint32_t tb = (uint64_t)max_b * RADIX < (uint64_t)max_tasks_lvl ? max_b * (uint32_t)RADIX : max_tasks_lvl;
+            if (pairs) launch_local_sorts<true>(ws, L, tb, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L, num_items);
+            else launch_local_sorts<false>(ws, L, tb, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L, num_items);
         }
     }
 }
@@ -1951,15 +2029,34 @@ static int msb_wide_sort(void *d_temp, K *keys, V *vals, uint64_t num_items, K *
     K *buf_k[2] = {keys, keys_alt};
     V *buf_v[2] = {vals, vals_alt};
     const uint32_t tiles_all = (uint32_t)((num_items + MW_TILE - 1) / MW_TILE);
+    MsbPeek *peek = msb_peek_get(s);           // a 64-bit key has 7 levels below the first; most of them are empty
+    uint32_t known_b = 0, known_tiles = 0;
+    bool known = false;
     for (int L = 1; L < KB; ++L) {
+        if (peek && peek->armed) {             // see msb_run_levels
+            peek->armed = false;
+            if (hipEventSynchronize(peek->ev) == hipSuccess) {
+                const unsigned long long pkd = *(volatile unsigned long long *)peek->host;
+                known_b = (uint32_t)(pkd >> 32); known_tiles = (uint32_t)pkd; known = true;
+                if (known_b == 0) break;
+            } else {
+                (void)hipGetLastError();
+                known = false;
+            }
+        }
         const uint32_t shift = (uint32_t)(key_bits - 8 - 8 * L);
         const K *sk = buf_k[L & 1];
         K *dk = buf_k[(L + 1) & 1];
         const V *sv = buf_v[L & 1];
         V *dv = buf_v[(L + 1) & 1];
         const bool last = L == KB - 1;
-        const uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
-        const uint32_t max_tiles = tiles_all + max_b;
+        uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
+        uint32_t max_tiles = tiles_all + max_b;
+        if (known && L >= 2) {
+            if (known_b < max_b) max_b = known_b;
+            if (known_tiles < max_tiles) max_tiles = known_tiles;
+            known = false;
+        }
         { KernelTimer kt(GS_K_MSB_HISTOGRAM, s);
           hipLaunchKernelGGL(msb_expand_kernel, dim3(max_b < 4096u ? max_b : 4096u), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr);
           const uint32_t hg_ub = max_tiles / MW_WAVES + 1;
@@ -1970,6 +2067,11 @@ static int msb_wide_sort(void *d_temp, K *keys, V *vals, uint64_t num_items, K *
           const uint32_t cg = max_b < 4096u ? max_b : 4096u;
           if (last) hipLaunchKernelGGL((msb_classify_kernel<true, false>), dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass);
           else hipLaunchKernelGGL((msb_classify_kernel<false, false>), dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass); }
+        if (peek && !last) {
+            hipLaunchKernelGGL(msb_peek_kernel, dim3(1), dim3(1), 0, s, ws, L + 1, peek->dev);
+            peek->armed = hipEventRecord(peek->ev, s) == hipSuccess;
+            if (!peek->armed) (void)hipGetLastError();
+        }
         { KernelTimer kt(GS_K_MSB_PARTITION, s);
           hipLaunchKernelGGL((mw_scatter_kernel<K, V>), dim3(max_tiles), dim3(MW_THREADS), 0, s, ws, L, sk, dk, sv, dv, shift, f, x); }
         if (!last) mw_launch_local_sorts<K, V>(ws, L, (const K *)dk, buf_k[0], (const V *)dv, buf_v[0], f, x, s);
