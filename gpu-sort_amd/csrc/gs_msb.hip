@@ -1452,12 +1452,14 @@ static inline bool onepass_possible(int min_bits, int b1, int onepass_bits)
 template <bool HAS_VALUES, bool STABLE = false>
 static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uint32_t *sk, uint32_t *dk, const uint32_t *sv,
                                uint32_t *dv, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out, hipStream_t s,
-                               int min_bits = 0, uint64_t num_items = 0)
+                               int min_bits = 0, uint64_t num_items = 0, const uint32_t *known_tasks = nullptr)
 {
     KernelTimer kt(GS_K_MSB_LOCAL_SORT, s);
     // grid-stride over the task list; few blocks suffice for the big classes (empty launches are not free)
+    // `known_tasks` (the host has looked, see MsbPeek): tasks per class -- empty classes are not launched at all
     auto grid_of = [&](int c) {
         uint64_t b = bound;
+        if (known_tasks && known_tasks[c] < b) b = known_tasks[c];
         if (num_items && c > 0) {
             const uint64_t lim = num_items / msb_class_cap(c - 1) + RADIX;     // a class-c task holds > cap(c-1) keys
             if (lim < b) b = lim;
@@ -1479,10 +1481,11 @@ static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uin
             { GS_LS1(C, HV, LS_ALL); }                                                                                \
         else { if (plain) GS_LS1P(C, HV, LS_ONEPASS, true); else GS_LS1(C, HV, LS_ONEPASS); GS_LS1(C, HV, LS_FLAGGED); } \
     } while (0)
-    GS_LS(0, HAS_VALUES);
-    GS_LS(1, HAS_VALUES);
-    GS_LS(2, HAS_VALUES);
-    if (!HAS_VALUES || GS_PAIR_CLASSES > 3) GS_LS(3, HAS_VALUES);
+    auto wanted = [&](int c) { return !known_tasks || known_tasks[c] != 0u; };
+    if (wanted(0)) GS_LS(0, HAS_VALUES);
+    if (wanted(1)) GS_LS(1, HAS_VALUES);
+    if (wanted(2)) GS_LS(2, HAS_VALUES);
+    if ((!HAS_VALUES || GS_PAIR_CLASSES > 3) && wanted(3)) GS_LS(3, HAS_VALUES);
 #undef GS_LS
 #undef GS_LS1
 #undef GS_LS1P
@@ -1507,9 +1510,11 @@ static inline bool msb_pivot_enabled()
 // work), and only then the host waits for that event -- the device has long passed it -- and either skips the remaining
 // levels or launches level L+1 with exact grids.  The device never idles; under graph capture (no host waits allowed)
 // and with GS_MSB_PEEK=0 the worst-case grids are used as before.
-__global__ void msb_peek_kernel(MsbWs ws, int L, unsigned long long *mailbox)
+__global__ void msb_peek_kernel(MsbWs ws, int L, unsigned long long *mailbox)   // L = the level about to be launched
 {
-    *mailbox = ws.level[L].packed;
+    mailbox[0] = ws.level[L].packed;
+    mailbox[1] = ((unsigned long long)ws.level[L - 1].task_count[1] << 32) | ws.level[L - 1].task_count[0];   // the tasks the
+    mailbox[2] = ((unsigned long long)ws.level[L - 1].task_count[3] << 32) | ws.level[L - 1].task_count[2];   // level before it emitted
     __threadfence_system();
 }
 struct MsbPeek {
@@ -1551,6 +1556,30 @@ static MsbPeek *msb_peek_get(hipStream_t s)
     return &pk;
 }
 
+// after level L-1's classification: ask for level L's size and level L-1's task counts
+static void msb_peek_arm(MsbPeek *pk, const MsbWs &ws, int L, hipStream_t s)
+{
+    if (!pk) return;
+    hipLaunchKernelGGL(msb_peek_kernel, dim3(1), dim3(1), 0, s, ws, L, pk->dev);
+    pk->armed = hipEventRecord(pk->ev, s) == hipSuccess;
+    if (!pk->armed) (void)hipGetLastError();
+}
+struct MsbLook { bool ok = false; uint32_t buckets = 0, tiles = 0, tasks[MSB_NCLASS] = {0, 0, 0, 0}; };
+// to be called once plenty of work has been enqueued behind the classification (the device is busy while the host waits)
+static MsbLook msb_peek_wait(MsbPeek *pk)
+{
+    MsbLook lk;
+    if (!pk || !pk->armed) return lk;
+    pk->armed = false;
+    if (hipEventSynchronize(pk->ev) != hipSuccess) { (void)hipGetLastError(); return lk; }
+    const volatile unsigned long long *m = pk->host;
+    const unsigned long long a = m[0], b = m[1], c = m[2];
+    lk.ok = true;
+    lk.buckets = (uint32_t)(a >> 32); lk.tiles = (uint32_t)a;
+    lk.tasks[0] = (uint32_t)b; lk.tasks[1] = (uint32_t)(b >> 32); lk.tasks[2] = (uint32_t)c; lk.tasks[3] = (uint32_t)(c >> 32);
+    return lk;
+}
+
 // `stop_level` (test access, gs_msb_classify_upto): return right after that level's classification; `allow_pivot` = false
 // keeps the heavy-hitter path off whatever the environment says.
 static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint32_t npieces, uint32_t *const buf_k[2],
@@ -1561,21 +1590,11 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
     const uint32_t tiles_all = (uint32_t)((num_items + MSB_TILE - 1) / MSB_TILE);
     const uint32_t max_tasks_lvl = ws.max_tasks;
     uint32_t *d_keys = buf_k[0], *d_vals = buf_v[0];
-    MsbPeek *peek = stop_level == 99 ? msb_peek_get(s) : nullptr;
+    // (not in the multi-GPU finish, npieces != 0: that path stays free of host waits between its collectives)
+    MsbPeek *peek = (stop_level == 99 && npieces == 0) ? msb_peek_get(s) : nullptr;
     uint32_t known_b = 0, known_tiles = 0;     // level L's exact bucket / tile counts when the look succeeded
     bool known = false;
     for (int L = 1; L <= 3; ++L) {
-        if (peek && peek->armed) {             // armed after level L-1's classification; the device is far past it by now
-            peek->armed = false;
-            if (hipEventSynchronize(peek->ev) == hipSuccess) {
-                const unsigned long long pkd = *(volatile unsigned long long *)peek->host;
-                known_b = (uint32_t)(pkd >> 32); known_tiles = (uint32_t)pkd; known = true;
-                if (known_b == 0) return;      // nothing left for this level or the ones below it
-            } else {
-                (void)hipGetLastError();
-                known = false;
-            }
-        }
         const int shift = 24 - 8 * L;
         const DigitSel dsel{shift, nullptr, 0, 0, 0u, 8, 0};
         uint32_t *sk = buf_k[L & 1], *dk = buf_k[(L + 1) & 1];
@@ -1613,11 +1632,7 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
           else if (pivot) hipLaunchKernelGGL((msb_classify_kernel<false, true>), dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass);
           else hipLaunchKernelGGL((msb_classify_kernel<false, false>), dim3(cg), dim3(256), 0, s, ws, L, (const uint32_t *)nullptr, nclass); }
         if (L == stop_level) return;
-        if (peek && !last) {
-            hipLaunchKernelGGL(msb_peek_kernel, dim3(1), dim3(1), 0, s, ws, L + 1, peek->dev);
-            peek->armed = hipEventRecord(peek->ev, s) == hipSuccess;
-            if (!peek->armed) (void)hipGetLastError();
-        }
+        if (!last) msb_peek_arm(peek, ws, L + 1, s);
         { KernelTimer kt(GS_K_MSB_PARTITION, s);
           const bool big = num_items > (1ull << 30);
           const uint32_t *svc = pairs ? (const uint32_t *)sv : (const uint32_t *)nullptr;
@@ -1629,10 +1644,17 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
 #undef GS_SC
         }
         if (!last) {
+            // the scatter is enqueued: now the host may wait for the look (the device is busy with the scatter)
+            const MsbLook lk = msb_peek_wait(peek);
             // a bucket emits at most 256 tasks
             const uint32_t tb = (uint64_t)max_b * RADIX < (uint64_t)max_tasks_lvl ? max_b * (uint32_t)RADIX : max_tasks_lvl;
-            if (pairs) launch_local_sorts<true>(ws, L, tb, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L, num_items);
-            else launch_local_sorts<false>(ws, L, tb, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L, num_items);
+            const uint32_t *kt_ = lk.ok ? lk.tasks : nullptr;
+            if (pairs) launch_local_sorts<true>(ws, L, tb, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L, num_items, kt_);
+            else launch_local_sorts<false>(ws, L, tb, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L, num_items, kt_);
+            if (lk.ok) {
+                if (lk.buckets == 0) return;   // nothing left for the levels below
+                known = true; known_b = lk.buckets; known_tiles = lk.tiles;
+            }
         }
     }
 }
@@ -2189,14 +2211,19 @@ static int msb_sort_impl(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint
         { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
           hipLaunchKernelGGL(msb_classify_kernel<false>, dim3(1), dim3(256), 0, s, ws, 0, (const uint32_t *)lw.totals, nclass); }
         if (stop_level == 0) { const int e0 = (int)hipGetLastError(); return e0 ? e0 : (synchronize ? (int)hipStreamSynchronize(s) : 0); }
+        MsbPeek *peek = stop_level == 99 ? msb_peek_get(s) : nullptr;      // see msb_run_levels
+        msb_peek_arm(peek, ws, 1, s);
         if ((e = lsb_downsweep(d_keys, d_keys_alt, d_vals, d_vals_alt, lw.spine, lw.prefix16, lw.totals, p0, s))) return e;
+        const MsbLook lk = msb_peek_wait(peek);                             // the device is busy with the scatter of level 0
         // upper bounds of what a level can hold (surplus blocks exit immediately)
         const uint32_t max_tasks_lvl = ws.max_tasks;
         const uint32_t task_grid0 = max_tasks_lvl < 2u * RADIX ? max_tasks_lvl : 2u * RADIX;   // level 0 emits <= 256 tasks
-        if (pairs) launch_local_sorts<true>(ws, 0, task_grid0, d_keys_alt, d_keys, d_vals_alt, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24, num_items);
-        else launch_local_sorts<false>(ws, 0, task_grid0, d_keys_alt, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24, num_items);
+        const uint32_t *kt0 = lk.ok ? lk.tasks : nullptr;
+        if (pairs) launch_local_sorts<true>(ws, 0, task_grid0, d_keys_alt, d_keys, d_vals_alt, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24, num_items, kt0);
+        else launch_local_sorts<false>(ws, 0, task_grid0, d_keys_alt, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24, num_items, kt0);
 
-        msb_run_levels(ws, num_items, pairs, /*pieces=*/0u, buf_k, buf_v, tw, s, stop_level, allow_pivot);
+        if (!(lk.ok && lk.buckets == 0))                                    // (no top-byte bucket outgrew the local sorts: done)
+            msb_run_levels(ws, num_items, pairs, /*pieces=*/0u, buf_k, buf_v, tw, s, stop_level, allow_pivot);
     }
     int err = (int)hipGetLastError();
     if (err) return err;

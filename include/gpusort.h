@@ -141,7 +141,11 @@ size_t gs_msb_temp_bytes(uint64_t num_items, int has_values);
  * these are the caller's INPUT arrays, as in the reference
  * (gpu_radix_sort.h:359-360, 505-506).  Enqueues on `stream` and, when
  * `synchronize` is nonzero, waits for completion like the reference does
- * (gpu_radix_sort.h:489-491).                                                */
+ * (gpu_radix_sort.h:489-491).  Unless `stream` is being captured into a HIP
+ * graph (or GS_MSB_PEEK=0 is set), the call also waits -- with the level's
+ * scatter already enqueued, so the device stays busy -- until each level's
+ * classification has run, to size or skip the next level's launches
+ * (DESIGN.md section 1); the result does not depend on it.                   */
 int gs_msb_sort_u32(void *d_temp, size_t temp_bytes,
                     uint32_t *d_keys, uint32_t *d_vals, uint64_t num_items,
                     uint32_t *d_keys_alt, uint32_t *d_vals_alt,
