@@ -1127,19 +1127,27 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                 }
             }
             if (!__syncthreads_or((int)overflow)) {
-                {   // offset inside the counter word: keys of the lower bins of the same word (pads compute garbage they never use)
-#pragma unroll
-                    for (int i = 0; i < KPT; ++i) {
-                        const uint32_t wd = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sm.hist) + (key[i] & wmask));
-                        pos[i] = __builtin_amdgcn_sad_u8(__builtin_amdgcn_ubfe(wd, 0u, (key[i] & 3u) << 3), 0u, pos[i]);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]), "+v"(key[i]));
-                __syncthreads();
-                // exclusive scan of the word sums, written over the words (WPT consecutive words per thread)
+                // exclusive scan of the word sums, written over the words (WPT consecutive words per thread).  A scanned word
+                // keeps its four counts next to its base -- {base : 16, four 4-bit counts : 16} -- so that ONE more LDS read per
+                // key yields both the word's base and the keys of the lower bins of the same word (a read of the raw counts
+                // before the scan + a read of the bases after it cost the LDS-bound kernel a fourth random access per key and a
+                // barrier).  A bin with more than 15 keys does not fit: the task is left to the general plan.
                 constexpr uint32_t WPT = ((1u << ONEPASS_BITS) >> 2) / THREADS;
                 static_assert(WPT >= 4 && WPT % 4 == 0, "words per thread");
+                static_assert(KPT * THREADS <= 65536, "a word's base must fit 16 bits");
+                // the ranks inside the bins are bytes: four per register while the scan needs the registers (64-VGPR budget)
+                uint32_t rk[(KPT + 3) / 4];
+#pragma unroll
+                for (int j = 0; j < (KPT + 3) / 4; ++j) {
+                    rk[j] = pos[4 * j];
+                    if (4 * j + 1 < KPT) rk[j] |= pos[4 * j + 1] << 8;
+                    if (4 * j + 2 < KPT) rk[j] |= pos[4 * j + 2] << 16;
+                    if (4 * j + 3 < KPT) rk[j] |= pos[4 * j + 3] << 24;
+                }
+#pragma unroll
+                for (int j = 0; j < (KPT + 3) / 4; ++j) asm volatile("" : "+v"(rk[j]));
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(key[i]));   // nothing derived from them stays live across the scan
                 const bool act = (uint32_t)tid * WPT < nwords;
                 uint32_t ssum = 0;
                 if (act) {
@@ -1156,22 +1164,31 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                 const uint32_t wsv = (lane < WAVES) ? sm.wtot[lane] : 0u;
                 const uint32_t wincl = wave_inclusive_scan(wsv);
                 uint32_t run = (uint32_t)__shfl((int)(wincl - wsv), w, WAVE) + inc - ssum;
+                uint32_t wide = 0;                         // any count above 15
+                auto pack = [&](uint32_t c) {              // bytes -> nibbles, base below them
+                    wide |= c & 0xf0f0f0f0u;
+                    const uint32_t nib = (c & 0xfu) | ((c >> 4) & 0xf0u) | ((c >> 8) & 0xf00u) | ((c >> 12) & 0xf000u);
+                    const uint32_t e = run | (nib << 16);
+                    run = __builtin_amdgcn_sad_u8(c, 0u, run);
+                    return e;
+                };
                 if (act) {
 #pragma unroll
                     for (uint32_t q = 0; q < WPT; q += 4) {
                         uint4 *p4 = reinterpret_cast<uint4 *>(sm.hist) + (((uint32_t)tid * WPT + q) >> 2);
                         const uint4 c4 = *p4;
                         uint4 e4;
-                        e4.x = run; run = __builtin_amdgcn_sad_u8(c4.x, 0u, run);
-                        e4.y = run; run = __builtin_amdgcn_sad_u8(c4.y, 0u, run);
-                        e4.z = run; run = __builtin_amdgcn_sad_u8(c4.z, 0u, run);
-                        e4.w = run; run = __builtin_amdgcn_sad_u8(c4.w, 0u, run);
+                        e4.x = pack(c4.x); e4.y = pack(c4.y); e4.z = pack(c4.z); e4.w = pack(c4.w);
                         *p4 = e4;
                     }
                 }
-                __syncthreads();
+                if (!__syncthreads_or((int)(wide != 0u))) {
 #pragma unroll
-                for (int i = 0; i < KPT; ++i) pos[i] += *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sm.hist) + (key[i] & wmask));
+                for (int i = 0; i < KPT; ++i) {
+                    const uint32_t wd = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sm.hist) + (key[i] & wmask));
+                    const uint32_t low = __builtin_amdgcn_ubfe(wd >> 16, 0u, (key[i] & 3u) << 2);          // the counts of the lower bins
+                    pos[i] = ((rk[i >> 2] >> (8 * (i & 3))) & 255u) + (wd & 0xffffu) + (low & 0xfu) + ((low >> 4) & 0xfu) + (low >> 8);
+                }
 #pragma unroll
                 for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]));
                 __syncthreads();                          // the counters are dead: the buffer takes the keys
@@ -1188,6 +1205,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                 }
                 __syncthreads();
                 done = true;
+                }
             }
         }
         if constexpr (MODE == LS_ONEPASS) {
