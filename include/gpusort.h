@@ -145,7 +145,9 @@ size_t gs_msb_temp_bytes(uint64_t num_items, int has_values);
  * graph (or GS_MSB_PEEK=0 is set), the call also waits -- with the level's
  * scatter already enqueued, so the device stays busy -- until each level's
  * classification has run, to size or skip the next level's launches
- * (DESIGN.md section 1); the result does not depend on it.                   */
+ * (DESIGN.md section 1); the result does not depend on it.  (A host wait is
+ * not allowed while ANOTHER stream of the process is being captured in the
+ * global capture mode: set GS_MSB_PEEK=0 there.)                             */
 int gs_msb_sort_u32(void *d_temp, size_t temp_bytes,
                     uint32_t *d_keys, uint32_t *d_vals, uint64_t num_items,
                     uint32_t *d_keys_alt, uint32_t *d_vals_alt,
