@@ -1718,9 +1718,14 @@ int small_stable_sort(void *scratch, size_t scratch_bytes, const uint32_t *kin, 
 // ---- segmented sort (cub::DeviceSegmentedRadixSort, dispatch_radix_sort.cuh:321-432)
 // Segments that fit a workgroup become stable local-sort tasks; the others become the buckets of ONE level
 // that is partitioned once per 8-bit digit, least significant first, with the level machinery above.
+// `tiny_cap` != 0: segments of up to tiny_cap elements go to a list of their own (one WAVE sorts such a segment,
+// seg_wave_sort_kernel): it grows downwards from the end of the class-0 task array and is counted in level[2].task_count[0]
+// (all lists together hold at most one task per segment, which is what the arrays are sized for).
+constexpr uint32_t SEG_TINY = 256;
 __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *__restrict__ seg_begin,
                                                            const int *__restrict__ seg_end, uint32_t nseg, int nclass,
-                                                           uint32_t sort_bits, uint32_t shift0, uint32_t num_items)
+                                                           uint32_t sort_bits, uint32_t shift0, uint32_t num_items,
+                                                           uint32_t tiny_cap = 0)
 {
     const uint32_t cap_max = ws.caps[nclass - 1];
     for (uint32_t base = blockIdx.x * blockDim.x; base < nseg; base += gridDim.x * blockDim.x) {
@@ -1735,7 +1740,18 @@ __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *
             if (hi > lo) { b = (uint32_t)lo; size = (uint32_t)(hi - lo); }
         }
         int cls = -1;
-        if (size != 0 && size <= cap_max) { cls = 0; while (ws.caps[cls] < size) ++cls; }
+        const bool tiny = size != 0 && size <= tiny_cap;
+        if (size != 0 && size <= cap_max && !tiny) { cls = 0; while (ws.caps[cls] < size) ++cls; }
+        {   // the tiny ones: one global atomic per wave
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(tiny);
+            if (m != 0) {
+                uint32_t first = 0;
+                if (count_lower_mask(m) == 0 && tiny) first = atomicAdd(&ws.level[2].task_count[0], (uint32_t)__popcll(m));
+                first = (uint32_t)__shfl((int)first, __builtin_ctzll(m), WAVE);
+                const uint32_t at = first + count_lower_mask(m);
+                if (tiny && at < ws.max_tasks) ws.tasks[0][ws.max_tasks - 1u - at] = MsbTask{b, size, sort_bits, shift0};
+            }
+        }
         // one global atomic per wave and class
 #pragma unroll
         for (int c = 0; c < MSB_NCLASS; ++c) {
@@ -1755,6 +1771,88 @@ __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *
     }
 }
 
+
+// Segments of up to 256 elements: ONE WAVE sorts a segment (4 elements per lane), four segments at a time per workgroup and no
+// workgroup barrier anywhere -- a 512-thread workgroup per 256-element segment spent its time in barriers (2^28 keys in 2^20
+// segments: 12.8 ms).  Stable LSD passes of 8 bits: wave64 ballot match + wave-private counters for the ranks, the 256 counters
+// scanned by the wave (4 per lane), elements exchanged through the wave's own 1-2 KiB of LDS.  LDS serves one wave's operations
+// in order, so a lane reads what another lane of its wave wrote earlier without any wait beyond the compiler fence.
+template <bool HAS_VALUES>
+__global__ __launch_bounds__(256) void seg_wave_sort_kernel(MsbWs ws, const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k,
+                                                            const uint32_t *__restrict__ src_v, uint32_t *__restrict__ dst_v, int f32_in,
+                                                            uint32_t xor_in, int f32_out, uint32_t xor_out)
+{
+    constexpr int WKPT = (int)SEG_TINY / WAVE;                      // 4
+    __shared__ __attribute__((aligned(16))) uint32_t hist[4][RADIX];
+    __shared__ uint32_t stage_k[4][SEG_TINY];
+    __shared__ uint32_t stage_v[HAS_VALUES ? 4 : 1][HAS_VALUES ? SEG_TINY : 1];
+    const int w = wave_id(), lane = lane_id();
+    uint32_t ntasks = ws.level[2].task_count[0];
+    if (ntasks > ws.max_tasks) ntasks = ws.max_tasks;
+    uint32_t *my = hist[w];
+    auto fence = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    for (uint32_t t = blockIdx.x * 4u + (uint32_t)w; t < ntasks; t += gridDim.x * 4u) {
+        const MsbTask Tv = ws.tasks[0][ws.max_tasks - 1u - t];
+        const uint32_t off = __builtin_amdgcn_readfirstlane(Tv.offset), size = __builtin_amdgcn_readfirstlane(Tv.size);
+        const uint32_t B = __builtin_amdgcn_readfirstlane(Tv.sort_bits), shift0 = __builtin_amdgcn_readfirstlane(Tv.pad);
+        uint32_t key[WKPT], val[HAS_VALUES ? WKPT : 1], pos[WKPT];
+        const uint32_t last = size - 1u;
+#pragma unroll
+        for (int i = 0; i < WKPT; ++i) {
+            const uint32_t idx = (uint32_t)(i * WAVE + lane), at = off + (idx < last ? idx : last);
+            key[i] = src_k[at];
+            if (HAS_VALUES) val[i] = src_v[at];
+        }
+#pragma unroll
+        for (int i = 0; i < WKPT; ++i) {
+            const uint32_t k = twiddle_in(key[i], f32_in, xor_in);
+            key[i] = ((uint32_t)(i * WAVE + lane) < size) ? k : 0xffffffffu;   // pads: last in position, largest in every digit
+        }
+        for (uint32_t done = 0; done < B; done += RADIX_BITS) {
+            const uint32_t bw = B - done < (uint32_t)RADIX_BITS ? B - done : (uint32_t)RADIX_BITS, sh = shift0 + done;
+            reinterpret_cast<uint4 *>(my)[lane] = make_uint4(0u, 0u, 0u, 0u);
+            fence();
+#pragma unroll
+            for (int i = 0; i < WKPT; ++i) {
+                const uint32_t d = __builtin_amdgcn_ubfe(key[i], sh, bw);
+                uint32_t lo, hi;
+                match_digit(d, lo, hi);
+                const uint32_t lower = count_lower(lo, hi);
+                pos[i] = my[d] + lower;
+                if (lower == 0) my[d] += (uint32_t)(__popc(lo) + __popc(hi));   // one lane per digit: no two writers of a word
+                fence();
+            }
+            {   // exclusive scan of the 256 counters, 4 per lane
+                const uint4 c = reinterpret_cast<const uint4 *>(my)[lane];
+                const uint32_t sum = c.x + c.y + c.z + c.w;
+                const uint32_t ex = wave_inclusive_scan(sum) - sum;
+                reinterpret_cast<uint4 *>(my)[lane] = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
+            }
+            fence();
+#pragma unroll
+            for (int i = 0; i < WKPT; ++i) {
+                const uint32_t at = pos[i] + my[__builtin_amdgcn_ubfe(key[i], sh, bw)];
+                stage_k[w][at] = key[i];
+                if (HAS_VALUES) stage_v[w][at] = val[i];
+            }
+            fence();
+#pragma unroll
+            for (int i = 0; i < WKPT; ++i) {
+                key[i] = stage_k[w][i * WAVE + lane];
+                if (HAS_VALUES) val[i] = stage_v[w][i * WAVE + lane];
+            }
+            fence();
+        }
+#pragma unroll
+        for (int i = 0; i < WKPT; ++i) {
+            const uint32_t idx = (uint32_t)(i * WAVE + lane);
+            if (idx < size) {
+                dst_k[off + idx] = twiddle_out(key[i], f32_out, xor_out);
+                if (HAS_VALUES) dst_v[off + idx] = val[i];
+            }
+        }
+    }
+}
 
 // ================================================================ wide MSB ==
 // rdxsrt_unstable_sort for 64-bit keys and / or 64-bit values: the reference instantiates its hybrid sort for 8-byte keys
@@ -2498,7 +2596,16 @@ int gs_segmented_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], 
     { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
       const uint32_t g = (num_segments + 255u) / 256u;
       hipLaunchKernelGGL(seg_classify_kernel, dim3(g < 4096u ? g : 4096u), dim3(256), 0, s, ws, d_begin_offsets, d_end_offsets,
-                         num_segments, nclass, (uint32_t)num_bits, (uint32_t)begin_bit, (uint32_t)num_items); }
+                         num_segments, nclass, (uint32_t)num_bits, (uint32_t)begin_bit, (uint32_t)num_items, SEG_TINY); }
+    {   // tiny segments: one wave each
+        KernelTimer kt(GS_K_MSB_LOCAL_SORT, s);
+        const uint32_t wg = (num_segments + 3u) / 4u;
+        const dim3 grid(wg < MSB_MAX_GRID ? wg : MSB_MAX_GRID);
+        if (pairs) hipLaunchKernelGGL(seg_wave_sort_kernel<true>, grid, dim3(256), 0, s, ws, (const uint32_t *)d_keys[sel], d_keys[fin],
+                                      (const uint32_t *)d_vals[sel], d_vals[fin], tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out);
+        else hipLaunchKernelGGL(seg_wave_sort_kernel<false>, grid, dim3(256), 0, s, ws, (const uint32_t *)d_keys[sel], d_keys[fin],
+                                (const uint32_t *)nullptr, (uint32_t *)nullptr, tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out);
+    }
     // small segments: one stable local sort each, straight into the final buffer
     if (pairs) launch_local_sorts<true, true>(ws, 1, num_segments, d_keys[sel], d_keys[fin], d_vals[sel], d_vals[fin], tw.f32_in,
                                               tw.xor_in, tw.f32_out, tw.xor_out, s);

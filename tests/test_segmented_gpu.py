@@ -115,6 +115,33 @@ def test_segments_signed_and_float_keys(gs, cuda, oracle):
         assert np.array_equal(ki[lo:hi].view(np.int32), np.sort(i[lo:hi])[::-1])
 
 
+@pytest.mark.parametrize("begin_bit,end_bit", [(0, 32), (3, 29), (8, 16), (31, 32)])
+def test_tiny_segments_one_wave_each(gs, cuda, oracle, begin_bit, end_bit):
+    """Segments of up to 256 elements are sorted by one wave each (seg_wave_sort_kernel): every size around the wave and the
+    256-element edges, next to segments that take the workgroup paths, keys and pairs, both directions, u32 / i32 / f32."""
+    sizes = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 0, 1, 256, 256, 5000, 256, 17, 9000, 3] * 6
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(offs[-1])
+    rng = np.random.default_rng(begin_bit * 41 + end_bit)
+    keys = oracle.gen_uniform(n, seed=11) & np.uint32(0xF0FFFF0F)        # duplicates inside the small segments
+    vals = oracle.gen_enumerated(n)
+    for desc in (False, True):
+        ranks = _expected(oracle, keys, offs, begin_bit, end_bit, desc)
+        ko, vo, _ = _run(gs, cuda, keys, vals, offs[:-1], offs[1:], begin_bit, end_bit, desc)
+        assert np.array_equal(vo, ranks.astype(np.uint32)), (begin_bit, end_bit, desc)   # stable
+        assert np.array_equal(ko, keys[ranks])
+        ko, _, _ = _run(gs, cuda, keys, None, offs[:-1], offs[1:], begin_bit, end_bit, desc)
+        assert np.array_equal(ko, keys[ranks])
+    if (begin_bit, end_bit) == (0, 32):
+        f = rng.standard_normal(n).astype(np.float32)
+        i = rng.integers(-2**31, 2**31, size=n, dtype=np.int64).astype(np.int32)
+        kf, _, _ = _run(gs, cuda, f.view(np.uint32), None, offs[:-1], offs[1:], desc=True, key_type=gs.GS_KEY_F32)
+        ki, _, _ = _run(gs, cuda, i.view(np.uint32), None, offs[:-1], offs[1:], key_type=gs.GS_KEY_I32)
+        for lo, hi in zip(offs[:-1], offs[1:]):
+            assert np.array_equal(kf[lo:hi].view(np.float32), np.sort(f[lo:hi])[::-1])
+            assert np.array_equal(ki[lo:hi].view(np.int32), np.sort(i[lo:hi]))
+
+
 def test_segments_large_properties(gs, cuda):
     """2^27 keys in 1000 uneven segments + one of 2^26: every segment sorted, multiset preserved (device checks)."""
     n = 1 << 27
