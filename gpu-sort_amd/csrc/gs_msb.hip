@@ -1718,10 +1718,11 @@ int small_stable_sort(void *scratch, size_t scratch_bytes, const uint32_t *kin, 
 // ---- segmented sort (cub::DeviceSegmentedRadixSort, dispatch_radix_sort.cuh:321-432)
 // Segments that fit a workgroup become stable local-sort tasks; the others become the buckets of ONE level
 // that is partitioned once per 8-bit digit, least significant first, with the level machinery above.
-// `tiny_cap` != 0: segments of up to tiny_cap elements go to a list of their own (one WAVE sorts such a segment,
-// seg_wave_sort_kernel): it grows downwards from the end of the class-0 task array and is counted in level[2].task_count[0]
-// (all lists together hold at most one task per segment, which is what the arrays are sized for).
-constexpr uint32_t SEG_TINY = 256;
+// `tiny_cap` != 0: segments of up to tiny_cap (256 / 512 / 1024) elements go to three lists of their own (one WAVE sorts such
+// a segment with 4 / 8 / 16 elements per lane, seg_wave_sort_kernel): list q grows downwards from the end of the class-q task
+// array and is counted in level[2].task_count[q] (all lists together hold at most one task per segment, which is what the
+// arrays are sized for).
+constexpr uint32_t SEG_TINY = 256;           // the smallest of the three; the largest is 4 * SEG_TINY
 __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *__restrict__ seg_begin,
                                                            const int *__restrict__ seg_end, uint32_t nseg, int nclass,
                                                            uint32_t sort_bits, uint32_t shift0, uint32_t num_items,
@@ -1740,17 +1741,17 @@ __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *
             if (hi > lo) { b = (uint32_t)lo; size = (uint32_t)(hi - lo); }
         }
         int cls = -1;
-        const bool tiny = size != 0 && size <= tiny_cap;
-        if (size != 0 && size <= cap_max && !tiny) { cls = 0; while (ws.caps[cls] < size) ++cls; }
-        {   // the tiny ones: one global atomic per wave
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(tiny);
-            if (m != 0) {
-                uint32_t first = 0;
-                if (count_lower_mask(m) == 0 && tiny) first = atomicAdd(&ws.level[2].task_count[0], (uint32_t)__popcll(m));
-                first = (uint32_t)__shfl((int)first, __builtin_ctzll(m), WAVE);
-                const uint32_t at = first + count_lower_mask(m);
-                if (tiny && at < ws.max_tasks) ws.tasks[0][ws.max_tasks - 1u - at] = MsbTask{b, size, sort_bits, shift0};
-            }
+        const int tq = (size == 0 || tiny_cap == 0 || size > 4u * tiny_cap) ? -1 : size <= tiny_cap ? 0 : size <= 2u * tiny_cap ? 1 : 2;
+        if (size != 0 && size <= cap_max && tq < 0) { cls = 0; while (ws.caps[cls] < size) ++cls; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {   // the wave-sized ones: one global atomic per wave and list
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(tq == q);
+            if (m == 0) continue;
+            uint32_t first = 0;
+            if (count_lower_mask(m) == 0 && tq == q) first = atomicAdd(&ws.level[2].task_count[q], (uint32_t)__popcll(m));
+            first = (uint32_t)__shfl((int)first, __builtin_ctzll(m), WAVE);
+            const uint32_t at = first + count_lower_mask(m);
+            if (tq == q && at < ws.max_tasks) ws.tasks[q][ws.max_tasks - 1u - at] = MsbTask{b, size, sort_bits, shift0};
         }
         // one global atomic per wave and class
 #pragma unroll
@@ -1777,22 +1778,22 @@ __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *
 // segments: 12.8 ms).  Stable LSD passes of 8 bits: wave64 ballot match + wave-private counters for the ranks, the 256 counters
 // scanned by the wave (4 per lane), elements exchanged through the wave's own 1-2 KiB of LDS.  LDS serves one wave's operations
 // in order, so a lane reads what another lane of its wave wrote earlier without any wait beyond the compiler fence.
-template <bool HAS_VALUES>
+template <bool HAS_VALUES, int WKPT /* 4, 8, 16: list 0, 1, 2 */>
 __global__ __launch_bounds__(256) void seg_wave_sort_kernel(MsbWs ws, const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k,
                                                             const uint32_t *__restrict__ src_v, uint32_t *__restrict__ dst_v, int f32_in,
                                                             uint32_t xor_in, int f32_out, uint32_t xor_out)
 {
-    constexpr int WKPT = (int)SEG_TINY / WAVE;                      // 4
+    constexpr int LIST = WKPT == 4 ? 0 : WKPT == 8 ? 1 : 2, CAP = WKPT * WAVE;
     __shared__ __attribute__((aligned(16))) uint32_t hist[4][RADIX];
-    __shared__ uint32_t stage_k[4][SEG_TINY];
-    __shared__ uint32_t stage_v[HAS_VALUES ? 4 : 1][HAS_VALUES ? SEG_TINY : 1];
+    __shared__ uint32_t stage_k[4][CAP];
+    __shared__ uint32_t stage_v[HAS_VALUES ? 4 : 1][HAS_VALUES ? CAP : 1];
     const int w = wave_id(), lane = lane_id();
-    uint32_t ntasks = ws.level[2].task_count[0];
+    uint32_t ntasks = ws.level[2].task_count[LIST];
     if (ntasks > ws.max_tasks) ntasks = ws.max_tasks;
     uint32_t *my = hist[w];
     auto fence = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
     for (uint32_t t = blockIdx.x * 4u + (uint32_t)w; t < ntasks; t += gridDim.x * 4u) {
-        const MsbTask Tv = ws.tasks[0][ws.max_tasks - 1u - t];
+        const MsbTask Tv = ws.tasks[LIST][ws.max_tasks - 1u - t];
         const uint32_t off = __builtin_amdgcn_readfirstlane(Tv.offset), size = __builtin_amdgcn_readfirstlane(Tv.size);
         const uint32_t B = __builtin_amdgcn_readfirstlane(Tv.sort_bits), shift0 = __builtin_amdgcn_readfirstlane(Tv.pad);
         uint32_t key[WKPT], val[HAS_VALUES ? WKPT : 1], pos[WKPT];
@@ -2601,10 +2602,12 @@ int gs_segmented_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], 
         KernelTimer kt(GS_K_MSB_LOCAL_SORT, s);
         const uint32_t wg = (num_segments + 3u) / 4u;
         const dim3 grid(wg < MSB_MAX_GRID ? wg : MSB_MAX_GRID);
-        if (pairs) hipLaunchKernelGGL(seg_wave_sort_kernel<true>, grid, dim3(256), 0, s, ws, (const uint32_t *)d_keys[sel], d_keys[fin],
-                                      (const uint32_t *)d_vals[sel], d_vals[fin], tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out);
-        else hipLaunchKernelGGL(seg_wave_sort_kernel<false>, grid, dim3(256), 0, s, ws, (const uint32_t *)d_keys[sel], d_keys[fin],
-                                (const uint32_t *)nullptr, (uint32_t *)nullptr, tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out);
+#define GS_WS(HV, K) hipLaunchKernelGGL((seg_wave_sort_kernel<HV, K>), grid, dim3(256), 0, s, ws, (const uint32_t *)d_keys[sel], d_keys[fin], \
+                                      HV ? (const uint32_t *)d_vals[sel] : (const uint32_t *)nullptr, HV ? d_vals[fin] : (uint32_t *)nullptr, \
+                                      tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out)
+        if (pairs) { GS_WS(true, 4); GS_WS(true, 8); GS_WS(true, 16); }
+        else { GS_WS(false, 4); GS_WS(false, 8); GS_WS(false, 16); }
+#undef GS_WS
     }
     // small segments: one stable local sort each, straight into the final buffer
     if (pairs) launch_local_sorts<true, true>(ws, 1, num_segments, d_keys[sel], d_keys[fin], d_vals[sel], d_vals[fin], tw.f32_in,

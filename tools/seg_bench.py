@@ -9,7 +9,7 @@ n = 1 << logn
 dev = "cuda:0"
 src = gs.generate_uniform_keys(n, device=dev)
 a, b = torch.empty_like(src), torch.empty_like(src)
-for seglen in (1 << 8, 1 << 12, 1 << 14, 1 << 16, 1 << 20, 1 << 24, n):
+for seglen in (1 << 5, 1 << 8, 1 << 9, 1 << 10, 1 << 11, 1 << 12, 1 << 14, 1 << 16, 1 << 20, 1 << 24, n):
     nseg = n // seglen
     offs = torch.arange(0, nseg + 1, dtype=torch.int64, device=dev).mul_(seglen).to(torch.int32)
     dk = gs.DoubleBuffer(a, b)
