@@ -1728,47 +1728,61 @@ __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *
                                                            uint32_t sort_bits, uint32_t shift0, uint32_t num_items,
                                                            uint32_t tiny_cap = 0)
 {
+    // 4 segments per thread, and ONE global atomic per workgroup step and list (1024 segments): the per-wave atomics on the list
+    // counters were the kernel's time for many segments (2^20 segments: 190 us)
+    constexpr int SPT = 4, NLIST = 3 + MSB_NCLASS;            // lists 0-2: one wave per segment; 3..: the local-sort classes
+    __shared__ uint32_t s_cnt[NLIST], s_base[NLIST];
     const uint32_t cap_max = ws.caps[nclass - 1];
-    for (uint32_t base = blockIdx.x * blockDim.x; base < nseg; base += gridDim.x * blockDim.x) {
-        const uint32_t sg = base + threadIdx.x;
-        uint32_t b = 0, size = 0;
-        if (sg < nseg) {
-            int lo = seg_begin[sg], hi = seg_end[sg];
-            // offsets outside [0, num_items] are the caller's error; clamp them so that they cannot become
-            // out-of-bounds accesses
-            if (lo < 0) lo = 0;
-            if (hi > (int)num_items) hi = (int)num_items;
-            if (hi > lo) { b = (uint32_t)lo; size = (uint32_t)(hi - lo); }
-        }
-        int cls = -1;
-        const int tq = (size == 0 || tiny_cap == 0 || size > 4u * tiny_cap) ? -1 : size <= tiny_cap ? 0 : size <= 2u * tiny_cap ? 1 : 2;
-        if (size != 0 && size <= cap_max && tq < 0) { cls = 0; while (ws.caps[cls] < size) ++cls; }
+    const int tid = threadIdx.x;
+    for (uint32_t base = blockIdx.x * (256u * SPT); base < nseg; base += gridDim.x * (256u * SPT)) {
+        if (tid < NLIST) s_cnt[tid] = 0;
+        __syncthreads();
+        uint32_t b[SPT], size[SPT], off[NLIST], cnt[NLIST];
+        int list[SPT];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {   // the wave-sized ones: one global atomic per wave and list
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(tq == q);
-            if (m == 0) continue;
-            uint32_t first = 0;
-            if (count_lower_mask(m) == 0 && tq == q) first = atomicAdd(&ws.level[2].task_count[q], (uint32_t)__popcll(m));
-            first = (uint32_t)__shfl((int)first, __builtin_ctzll(m), WAVE);
-            const uint32_t at = first + count_lower_mask(m);
-            if (tq == q && at < ws.max_tasks) ws.tasks[q][ws.max_tasks - 1u - at] = MsbTask{b, size, sort_bits, shift0};
-        }
-        // one global atomic per wave and class
+        for (int q = 0; q < NLIST; ++q) cnt[q] = 0;
 #pragma unroll
-        for (int c = 0; c < MSB_NCLASS; ++c) {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == c);
-            if (m == 0) continue;
-            uint32_t first = 0;
-            if (count_lower_mask(m) == 0 && cls == c) first = atomicAdd(&ws.level[1].task_count[c], (uint32_t)__popcll(m));
-            first = (uint32_t)__shfl((int)first, __builtin_ctzll(m), WAVE);
-            if (cls == c && first + count_lower_mask(m) < ws.max_tasks)
-                ws.tasks[c][first + count_lower_mask(m)] = MsbTask{b, size, sort_bits, shift0};
+        for (int j = 0; j < SPT; ++j) {
+            const uint32_t sg = base + (uint32_t)tid * SPT + j;
+            b[j] = 0; size[j] = 0; list[j] = -1;
+            if (sg < nseg) {
+                int lo = seg_begin[sg], hi = seg_end[sg];
+                // offsets outside [0, num_items] are the caller's error; clamp them so that they cannot become
+                // out-of-bounds accesses
+                if (lo < 0) lo = 0;
+                if (hi > (int)num_items) hi = (int)num_items;
+                if (hi > lo) { b[j] = (uint32_t)lo; size[j] = (uint32_t)(hi - lo); }
+            }
+            const uint32_t sz = size[j];
+            if (sz != 0 && tiny_cap != 0 && sz <= 4u * tiny_cap) list[j] = sz <= tiny_cap ? 0 : sz <= 2u * tiny_cap ? 1 : 2;
+            else if (sz != 0 && sz <= cap_max) { int c = 0; while (ws.caps[c] < sz) ++c; list[j] = 3 + c; }
+            else if (sz > cap_max) {          // a bucket of the level (rare: one atomic each)
+                const uint32_t tiles = ws_tiles_of(ws, sz);
+                const unsigned long long old = atomicAdd(&ws.level[1].packed, (1ull << 32) | tiles);
+                if ((uint32_t)(old >> 32) < ws.max_buckets) ws.buckets[1][(uint32_t)(old >> 32)] = MsbBucket{b[j], sz, (uint32_t)old, tiles};
+            }
+#pragma unroll
+            for (int q = 0; q < NLIST; ++q) cnt[q] += list[j] == q ? 1u : 0u;
         }
-        if (size > cap_max) {
-            const uint32_t tiles = ws_tiles_of(ws, size);
-            const unsigned long long old = atomicAdd(&ws.level[1].packed, (1ull << 32) | tiles);
-            if ((uint32_t)(old >> 32) < ws.max_buckets) ws.buckets[1][(uint32_t)(old >> 32)] = MsbBucket{b, size, (uint32_t)old, tiles};
+#pragma unroll
+        for (int q = 0; q < NLIST; ++q) off[q] = cnt[q] ? atomicAdd(&s_cnt[q], cnt[q]) : 0u;       // LDS
+        __syncthreads();
+        if (tid < NLIST && s_cnt[tid] != 0u)
+            s_base[tid] = atomicAdd(tid < 3 ? &ws.level[2].task_count[tid] : &ws.level[1].task_count[tid - 3], s_cnt[tid]);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+#pragma unroll
+            for (int q = 0; q < NLIST; ++q) {
+                if (list[j] != q) continue;
+                const uint32_t at = s_base[q] + off[q]++;
+                if (at < ws.max_tasks) {
+                    if (q < 3) ws.tasks[q][ws.max_tasks - 1u - at] = MsbTask{b[j], size[j], sort_bits, shift0};
+                    else ws.tasks[q - 3][at] = MsbTask{b[j], size[j], sort_bits, shift0};
+                }
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -2240,7 +2254,7 @@ static int seg_wide_sort(void *d_temp, void *d_keys[2], void *d_vals[2], int *se
     hipError_t e = zero_async(ws.level, MSB_LEVELS * sizeof(MsbLevel), s);
     if (e != hipSuccess) return (int)e;
     { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
-      const uint32_t g = (num_segments + 255u) / 256u;
+      const uint32_t g = (num_segments + 1023u) / 1024u;
       hipLaunchKernelGGL(seg_classify_kernel, dim3(g < 4096u ? g : 4096u), dim3(256), 0, s, ws, d_begin_offsets, d_end_offsets,
                          num_segments, nclass, (uint32_t)num_bits, (uint32_t)begin_bit, (uint32_t)num_items); }
     mw_launch_local_sorts<K, V>(ws, 1, (const K *)d_keys[sel], (K *)d_keys[fin], pairs ? (const V *)d_vals[sel] : nullptr,
@@ -2595,7 +2609,7 @@ int gs_segmented_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], 
     hipError_t e = zero_async(ws.level, MSB_LEVELS * sizeof(MsbLevel), s);
     if (e != hipSuccess) return (int)e;
     { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
-      const uint32_t g = (num_segments + 255u) / 256u;
+      const uint32_t g = (num_segments + 1023u) / 1024u;
       hipLaunchKernelGGL(seg_classify_kernel, dim3(g < 4096u ? g : 4096u), dim3(256), 0, s, ws, d_begin_offsets, d_end_offsets,
                          num_segments, nclass, (uint32_t)num_bits, (uint32_t)begin_bit, (uint32_t)num_items, SEG_TINY); }
     {   // tiny segments: one wave each
