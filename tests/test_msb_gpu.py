@@ -248,3 +248,37 @@ def test_msb_sort_is_capturable_in_a_hip_graph(gs, cuda, oracle, n, pairs):
         assert np.array_equal(got, np.sort(keys))
         if pairs:
             assert oracle.msb_check_pairs_enumerated(keys, got, to_u32(seq.sorted_values)[:n]) == 0
+
+
+def test_look_at_the_next_level_does_not_change_results():
+    """Outside a graph capture the MSB sorts look at the next level's size (a pinned host word written after each level's
+    classification) and skip empty levels / launch exact grids; GS_MSB_PEEK=0 keeps the worst-case grids.  The switch is read
+    once per process, so both settings run in child processes: same sorted keys (checksums) for sizes that end after level 0,
+    1, 2 and 3 and for uniform and Zipf keys, and the census of the last sort is the same."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys, json, torch
+sys.path.insert(0, %r)
+import gpu_sort_amd as gs
+from gpu_sort_amd.msb import msb_census
+out = []
+dev = torch.device("cuda:0")
+for n, gen in ((30000, gs.generate_uniform_keys), (1 << 20, gs.generate_uniform_keys), ((1 << 24) + 77, gs.generate_uniform_keys),
+               ((1 << 24) + 5, gs.generate_zipf_keys), ((1 << 22) + 1, lambda n, device: gs.generate_random_keys(n, entropy_level=5, device=device))):
+    a = gen(n, device=dev); b = torch.empty_like(a)
+    ref = torch.sort(a.to(torch.int64) & 0xffffffff).values
+    dm = torch.empty(gs.lib.gs_msb_temp_bytes(n, 0), dtype=torch.uint8, device=dev)
+    seq = gs.rdxsrt_unstable_sort(a, None, n, b, None, pre_allocated_dm=dm)
+    got = seq.sorted_keys.to(torch.int64) & 0xffffffff
+    cen = msb_census(dm, n)
+    out.append([bool(torch.equal(got, ref)), [c["keys"] for c in cen], [c["task_keys"] for c in cen]])
+print(json.dumps(out))
+""" % root
+    res = []
+    for peek in ("1", "0"):
+        env = dict(os.environ, GS_MSB_PEEK=peek)
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env, check=True)
+        res.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert all(case[0] for case in res[0]) and all(case[0] for case in res[1])
+    assert res[0] == res[1]
