@@ -1,3 +1,4 @@
+"""One segmented sort of 2^28 keys in equal segments (to put under rocprofv3): python tools/seg_one.py [segment length]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
