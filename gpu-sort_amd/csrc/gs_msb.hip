@@ -1719,9 +1719,10 @@ int small_stable_sort(void *scratch, size_t scratch_bytes, const uint32_t *kin, 
 // Segments that fit a workgroup become stable local-sort tasks; the others become the buckets of ONE level
 // that is partitioned once per 8-bit digit, least significant first, with the level machinery above.
 // `tiny_cap` != 0: segments of up to tiny_cap (256 / 512 / 1024) elements go to three lists of their own (one WAVE sorts such
-// a segment with 4 / 8 / 16 elements per lane, seg_wave_sort_kernel): list q grows downwards from the end of the class-q task
-// array and is counted in level[2].task_count[q] (all lists together hold at most one task per segment, which is what the
-// arrays are sized for).
+// a segment with 4 / 8 / 16 elements per lane, seg_wave_sort_kernel) and those of up to 64 elements to a fourth (a wave sorts
+// four of them at a time, seg_wave4_sort_kernel): list q grows downwards from the end of the class-q task array and is
+// counted in level[2].task_count[q] (all lists together hold at most one task per segment, which is what the arrays are
+// sized for).
 constexpr uint32_t SEG_TINY = 256;           // the smallest of the three; the largest is 4 * SEG_TINY
 __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *__restrict__ seg_begin,
                                                            const int *__restrict__ seg_end, uint32_t nseg, int nclass,
@@ -1730,7 +1731,7 @@ __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *
 {
     // 4 segments per thread, and ONE global atomic per workgroup step and list (1024 segments): the per-wave atomics on the list
     // counters were the kernel's time for many segments (2^20 segments: 190 us)
-    constexpr int SPT = 4, NLIST = 3 + MSB_NCLASS;            // lists 0-2: one wave per segment; 3..: the local-sort classes
+    constexpr int NW = 4, SPT = 4, NLIST = NW + MSB_NCLASS;   // lists 0-2: one wave per segment, 3: four segments per wave; 4..: the classes
     __shared__ uint32_t s_cnt[NLIST], s_base[NLIST];
     const uint32_t cap_max = ws.caps[nclass - 1];
     const int tid = threadIdx.x;
@@ -1754,8 +1755,8 @@ __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *
                 if (hi > lo) { b[j] = (uint32_t)lo; size[j] = (uint32_t)(hi - lo); }
             }
             const uint32_t sz = size[j];
-            if (sz != 0 && tiny_cap != 0 && sz <= 4u * tiny_cap) list[j] = sz <= tiny_cap ? 0 : sz <= 2u * tiny_cap ? 1 : 2;
-            else if (sz != 0 && sz <= cap_max) { int c = 0; while (ws.caps[c] < sz) ++c; list[j] = 3 + c; }
+            if (sz != 0 && tiny_cap != 0 && sz <= 4u * tiny_cap) list[j] = sz <= (uint32_t)WAVE ? 3 : sz <= tiny_cap ? 0 : sz <= 2u * tiny_cap ? 1 : 2;
+            else if (sz != 0 && sz <= cap_max) { int c = 0; while (ws.caps[c] < sz) ++c; list[j] = NW + c; }
             else if (sz > cap_max) {          // a bucket of the level (rare: one atomic each)
                 const uint32_t tiles = ws_tiles_of(ws, sz);
                 const unsigned long long old = atomicAdd(&ws.level[1].packed, (1ull << 32) | tiles);
@@ -1768,7 +1769,7 @@ __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *
         for (int q = 0; q < NLIST; ++q) off[q] = cnt[q] ? atomicAdd(&s_cnt[q], cnt[q]) : 0u;       // LDS
         __syncthreads();
         if (tid < NLIST && s_cnt[tid] != 0u)
-            s_base[tid] = atomicAdd(tid < 3 ? &ws.level[2].task_count[tid] : &ws.level[1].task_count[tid - 3], s_cnt[tid]);
+            s_base[tid] = atomicAdd(tid < NW ? &ws.level[2].task_count[tid] : &ws.level[1].task_count[tid - NW], s_cnt[tid]);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
@@ -1777,8 +1778,8 @@ __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *
                 if (list[j] != q) continue;
                 const uint32_t at = s_base[q] + off[q]++;
                 if (at < ws.max_tasks) {
-                    if (q < 3) ws.tasks[q][ws.max_tasks - 1u - at] = MsbTask{b[j], size[j], sort_bits, shift0};
-                    else ws.tasks[q - 3][at] = MsbTask{b[j], size[j], sort_bits, shift0};
+                    if (q < NW) ws.tasks[q][ws.max_tasks - 1u - at] = MsbTask{b[j], size[j], sort_bits, shift0};
+                    else ws.tasks[q - NW][at] = MsbTask{b[j], size[j], sort_bits, shift0};
                 }
             }
         }
@@ -1864,6 +1865,92 @@ __global__ __launch_bounds__(256) void seg_wave_sort_kernel(MsbWs ws, const uint
             if (idx < size) {
                 dst_k[off + idx] = twiddle_out(key[i], f32_out, xor_out);
                 if (HAS_VALUES) dst_v[off + idx] = val[i];
+            }
+        }
+    }
+}
+
+// Segments of up to 64 elements: a wave sorts FOUR of them at a time, one per round of its four elements per lane -- every
+// segment has its own 256 counters and its own 64 slots of the wave's LDS, and a segment's elements sit in one round, so the
+// rank inside a digit is just the count of equal digits in the lower lanes.  (One such segment per wave left three quarters of
+// the wave idle: 2^23 segments of 32 keys took 11 ms.)
+template <bool HAS_VALUES>
+__global__ __launch_bounds__(256) void seg_wave4_sort_kernel(MsbWs ws, const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k,
+                                                             const uint32_t *__restrict__ src_v, uint32_t *__restrict__ dst_v, int f32_in,
+                                                             uint32_t xor_in, int f32_out, uint32_t xor_out)
+{
+    constexpr int NS = 4;                                          // segments per wave and step
+    __shared__ __attribute__((aligned(16))) uint32_t hist[4][NS][RADIX];
+    __shared__ uint32_t stage_k[4][NS * WAVE];
+    __shared__ uint32_t stage_v[HAS_VALUES ? 4 : 1][HAS_VALUES ? NS * WAVE : 1];
+    const int w = wave_id(), lane = lane_id();
+    uint32_t ntasks = ws.level[2].task_count[3];
+    if (ntasks > ws.max_tasks) ntasks = ws.max_tasks;
+    auto fence = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    for (uint32_t t0 = (blockIdx.x * 4u + (uint32_t)w) * NS; t0 < ntasks; t0 += gridDim.x * 4u * NS) {
+        uint32_t off[NS], size[NS], key[NS], val[HAS_VALUES ? NS : 1], pos[NS];
+        uint32_t B = 0, shift0 = 0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            off[i] = 0; size[i] = 0;
+            if (t0 + i < ntasks) {                                 // wave-uniform
+                const MsbTask Tv = ws.tasks[3][ws.max_tasks - 1u - (t0 + i)];
+                off[i] = __builtin_amdgcn_readfirstlane(Tv.offset); size[i] = __builtin_amdgcn_readfirstlane(Tv.size);
+                B = __builtin_amdgcn_readfirstlane(Tv.sort_bits); shift0 = __builtin_amdgcn_readfirstlane(Tv.pad);   // the same for every segment of a call
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            key[i] = 0xffffffffu;
+            if (HAS_VALUES) val[i] = 0;
+            if ((uint32_t)lane < size[i]) {
+                key[i] = twiddle_in(src_k[off[i] + lane], f32_in, xor_in);
+                if (HAS_VALUES) val[i] = src_v[off[i] + lane];
+            } else {
+                key[i] = 0xffffffffu;                              // pads: behind the segment's elements, largest in every digit
+            }
+        }
+        for (uint32_t done = 0; done < B; done += RADIX_BITS) {
+            const uint32_t bw = B - done < (uint32_t)RADIX_BITS ? B - done : (uint32_t)RADIX_BITS, sh = shift0 + done;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) reinterpret_cast<uint4 *>(hist[w][i])[lane] = make_uint4(0u, 0u, 0u, 0u);
+            fence();
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const uint32_t d = __builtin_amdgcn_ubfe(key[i], sh, bw);
+                uint32_t lo, hi;
+                match_digit(d, lo, hi);
+                pos[i] = count_lower(lo, hi);
+                if (pos[i] == 0) hist[w][i][d] = (uint32_t)(__popc(lo) + __popc(hi));
+            }
+            fence();
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {   // exclusive scan of segment i's 256 counters, 4 per lane
+                const uint4 c = reinterpret_cast<const uint4 *>(hist[w][i])[lane];
+                const uint32_t sum = c.x + c.y + c.z + c.w;
+                const uint32_t ex = wave_inclusive_scan(sum) - sum;
+                reinterpret_cast<uint4 *>(hist[w][i])[lane] = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
+            }
+            fence();
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const uint32_t at = (uint32_t)(i * WAVE) + pos[i] + hist[w][i][__builtin_amdgcn_ubfe(key[i], sh, bw)];
+                stage_k[w][at] = key[i];
+                if (HAS_VALUES) stage_v[w][at] = val[i];
+            }
+            fence();
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                key[i] = stage_k[w][i * WAVE + lane];
+                if (HAS_VALUES) val[i] = stage_v[w][i * WAVE + lane];
+            }
+            fence();
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if ((uint32_t)lane < size[i]) {
+                dst_k[off[i] + lane] = twiddle_out(key[i], f32_out, xor_out);
+                if (HAS_VALUES) dst_v[off[i] + lane] = val[i];
             }
         }
     }
@@ -2622,6 +2709,12 @@ int gs_segmented_sort_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys[2], 
         if (pairs) { GS_WS(true, 4); GS_WS(true, 8); GS_WS(true, 16); }
         else { GS_WS(false, 4); GS_WS(false, 8); GS_WS(false, 16); }
 #undef GS_WS
+        const uint32_t wg4 = (num_segments + 15u) / 16u;
+        const dim3 grid4(wg4 < MSB_MAX_GRID ? wg4 : MSB_MAX_GRID);
+        if (pairs) hipLaunchKernelGGL(seg_wave4_sort_kernel<true>, grid4, dim3(256), 0, s, ws, (const uint32_t *)d_keys[sel], d_keys[fin],
+                                      (const uint32_t *)d_vals[sel], d_vals[fin], tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out);
+        else hipLaunchKernelGGL(seg_wave4_sort_kernel<false>, grid4, dim3(256), 0, s, ws, (const uint32_t *)d_keys[sel], d_keys[fin],
+                                (const uint32_t *)nullptr, (uint32_t *)nullptr, tw.f32_in, tw.xor_in, tw.f32_out, tw.xor_out);
     }
     // small segments: one stable local sort each, straight into the final buffer
     if (pairs) launch_local_sorts<true, true>(ws, 1, num_segments, d_keys[sel], d_keys[fin], d_vals[sel], d_vals[fin], tw.f32_in,

@@ -118,8 +118,8 @@ def test_segments_signed_and_float_keys(gs, cuda, oracle):
 @pytest.mark.parametrize("begin_bit,end_bit", [(0, 32), (3, 29), (8, 16), (31, 32)])
 def test_tiny_segments_one_wave_each(gs, cuda, oracle, begin_bit, end_bit):
     """Segments of up to 256 / 512 / 1024 elements are sorted by one wave each (seg_wave_sort_kernel, 4 / 8 / 16 elements per
-    lane): every size around the wave and the three list edges, next to segments that take the workgroup paths, keys and
-    pairs, both directions, u32 / i32 / f32."""
+    lane), those of up to 64 elements four at a time by one wave (seg_wave4_sort_kernel): every size around the wave and the
+    list edges, next to segments that take the workgroup paths, keys and pairs, both directions, u32 / i32 / f32."""
     sizes = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 0, 1, 256, 511, 512, 513, 5000, 1023, 1024, 1025, 17, 9000, 3, 700] * 5
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     n = int(offs[-1])
