@@ -301,7 +301,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void lsb_scan_kernel(uint32_t *__rest
 template <bool HAS_VALUES>
 struct DownsweepSmem {
     uint32_t whist[LSB_WAVES][RADIX];                     // wave-private digit counters, then bases (byte offsets)
+#ifdef GS_EXP_ALLWAVE_KEYS
+    uint16_t wbase[LSB_WAVES][RADIX];
+#else
     uint16_t wbase[HAS_VALUES ? LSB_WAVES : 1][RADIX];    // pairs: tile-absolute base of (wave, digit), < 8192
+#endif
     uint32_t gbase[RADIX];                                // global offset of digit run - tile-local start
     uint32_t stage[LSB_TILE * (HAS_VALUES ? 2 : 1)];      // tile in rank order; pairs interleaved {key,val}
 };
@@ -345,7 +349,11 @@ __device__ __forceinline__ void downsweep_tile(DownsweepSmem<HAS_VALUES> &sm, co
     const uint32_t *__restrict__ totals, const PassParams &p, const uint64_t *__restrict__ sc, uint32_t tag,
     uint32_t *__restrict__ error_word, const uint32_t tid_ = threadIdx.x)
 {
+#ifdef GS_EXP_ALLWAVE_KEYS
+    constexpr bool ALLWAVE = true;          // experiment: every wave computes its own bases for keys too (no second barrier)
+#else
     constexpr bool ALLWAVE = HAS_VALUES;   // see step 3
+#endif
 
     [[maybe_unused]] const int tid = (int)tid_;
     const int lane = (int)(tid_ & 63u), w = (int)(tid_ >> 6);
@@ -586,6 +594,8 @@ __device__ __forceinline__ void downsweep_tile(DownsweepSmem<HAS_VALUES> &sm, co
         for (int i = 0; i < LSB_KPT; ++i) {
             if (HAS_VALUES) {
                 reinterpret_cast<uint2 *>(sm.stage)[pos[i] + wb[i]] = make_uint2(key[i], val[i]);
+            } else if (ALLWAVE) {
+                sm.stage[pos[i] + wb[i]] = key[i];
             } else {
                 const uint32_t at = (pos[i] << 2) + wb[i];       // bytes
                 *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(sm.stage) + at) = key[i];
@@ -641,13 +651,18 @@ __device__ __forceinline__ void downsweep_tile(DownsweepSmem<HAS_VALUES> &sm, co
 #endif
 }
 
+// The arguments the first instructions need (key count, digit position, spine row length, the key pointers) come first
+// and as plain scalars: with -mllvm -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave, so the key loads
+// are issued without a scalar-load round trip (two dependent ones before).  `p` still carries everything else.
 template <bool HAS_VALUES, bool TAIL, int TW, bool BIG>
 __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep_kernel(
-    const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ vals_in,
-    uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ spine, const uint16_t *__restrict__ prefix16,
-    const uint32_t *__restrict__ totals, PassParams p)
+    const uint32_t n_, const uint32_t shift_, const uint32_t bits_, const uint32_t grid_,
+    const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ totals,
+    const uint32_t *__restrict__ spine, const uint16_t *__restrict__ prefix16, const uint32_t *__restrict__ vals_in,
+    uint32_t *__restrict__ vals_out, PassParams p)
 {
     __shared__ __attribute__((aligned(16))) DownsweepSmem<HAS_VALUES> sm;
+    p.n = n_; p.shift = shift_; p.bits = bits_; p.grid = grid_;
     const uint32_t full_tiles = p.n / (uint32_t)LSB_TILE;
 #if defined(GS_EXP_TPB) || defined(GS_EXP_PERSIST)
     // experiment builds only (profiles/r02_lsb_structure_experiments.txt): a block walks several tiles, plainly one after the other
@@ -673,7 +688,7 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
         return;
     }
 #endif
-    if (!TAIL && blockIdx.x >= full_tiles) return;
+    if (!TAIL && blockIdx.x >= full_tiles) return;   // (n_ is preloaded: two scalar instructions, no memory wait)
     const uint32_t t = TAIL ? full_tiles : tile_of_item(blockIdx.x, full_tiles);
     downsweep_tile<HAS_VALUES, TAIL, TW, BIG, false>(sm, t, keys_in, keys_out, vals_in, vals_out, spine, prefix16, totals, p,
                                                      nullptr, 0u, nullptr);
@@ -963,11 +978,11 @@ static void launch_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t
     const dim3 grid(p.ds_grid);
 #endif
     if (vin)
-        hipLaunchKernelGGL((lsb_downsweep_kernel<true, false, TW, BIG>), grid, block, 0, s, kin, kout, vin, vout,
-                           spine, prefix16, totals, p);
+        hipLaunchKernelGGL((lsb_downsweep_kernel<true, false, TW, BIG>), grid, block, 0, s, p.n, p.shift, p.bits, p.grid, kin, kout,
+                           totals, spine, prefix16, vin, vout, p);
     else
-        hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, TW, BIG>), grid, block, 0, s, kin, kout, vin, vout,
-                           spine, prefix16, totals, p);
+        hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, TW, BIG>), grid, block, 0, s, p.n, p.shift, p.bits, p.grid, kin, kout,
+                           totals, spine, prefix16, vin, vout, p);
 }
 
 static void launch_downsweep_tail(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
@@ -975,11 +990,11 @@ static void launch_downsweep_tail(const uint32_t *kin, uint32_t *kout, const uin
 {
     const dim3 block(LSB_THREADS);   // one block, the general variant
     if (vin)
-        hipLaunchKernelGGL((lsb_downsweep_kernel<true, true, 2, true>), dim3(1), block, 0, s, kin, kout, vin, vout,
-                           (const uint32_t *)nullptr, (const uint16_t *)nullptr, totals, p);
+        hipLaunchKernelGGL((lsb_downsweep_kernel<true, true, 2, true>), dim3(1), block, 0, s, p.n, p.shift, p.bits, p.grid, kin, kout,
+                           totals, (const uint32_t *)nullptr, (const uint16_t *)nullptr, vin, vout, p);
     else
-        hipLaunchKernelGGL((lsb_downsweep_kernel<false, true, 2, true>), dim3(1), block, 0, s, kin, kout, vin, vout,
-                           (const uint32_t *)nullptr, (const uint16_t *)nullptr, totals, p);
+        hipLaunchKernelGGL((lsb_downsweep_kernel<false, true, 2, true>), dim3(1), block, 0, s, p.n, p.shift, p.bits, p.grid, kin, kout,
+                           totals, (const uint32_t *)nullptr, (const uint16_t *)nullptr, vin, vout, p);
 }
 
 int lsb_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, const uint32_t *spine,

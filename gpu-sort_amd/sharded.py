@@ -41,17 +41,23 @@ MAX_MSG = 3 << 26
 def compute_splits(hist_all, world):
     """hist_all: (world, nbins) counts.  Returns (dest_of_bin uint8[nbins], recv_total per rank).
 
-    Bins are assigned to ranks in key order; bin b goes to rank floor(G * keys_before_b / N),
-    so every rank owns a contiguous key range and totals are balanced to within one bin."""
-    tot = hist_all.sum(axis=0).astype(np.uint64)
-    n = int(tot.sum())
-    before = np.cumsum(tot, dtype=np.uint64) - tot
-    if n == 0:
-        dest = np.zeros(tot.size, np.uint8)
-    else:
-        dest = np.minimum((before.astype(np.float64) * world / n).astype(np.int64), world - 1).astype(np.uint8)
-        dest = np.maximum.accumulate(dest)          # monotone by construction; keep it so under rounding
-    per_rank = np.array([int(tot[dest == r].sum()) for r in range(world)], dtype=np.int64)
+    Bins are assigned to ranks in key order; bin b goes to rank floor(world * keys_before_b / N),
+    so every rank owns a contiguous key range and totals are balanced to within one bin.  The quotient is
+    taken in exact integer arithmetic (Python ints), bit for bit what the C++ host computes with 128-bit
+    integers (gs_sharded_compute_splits, csrc_rccl/gs_sharded_rccl.cpp): two hosts of one exchange must never
+    disagree by a bucket, which a float64 quotient could do next to an exact multiple."""
+    tot = [int(x) for x in np.asarray(hist_all).sum(axis=0, dtype=np.uint64)]
+    n = sum(tot)
+    dest = np.zeros(len(tot), np.uint8)
+    per_rank = np.zeros(world, dtype=np.int64)
+    before, prev = 0, 0
+    for b, c in enumerate(tot):
+        d = min(before * world // n, world - 1) if n else 0
+        d = max(d, prev)                             # monotone by construction; kept so for the last rank's clamp
+        prev = d
+        dest[b] = d
+        per_rank[d] += c
+        before += c
     return dest, per_rank
 
 
@@ -211,6 +217,39 @@ def _all_to_all_lists(outs, ins, group):
             pos += o.numel()
         return None
     return dist.all_to_all(outs, ins, group=group, async_op=True)
+
+
+def communicator_selftest(device, group=None, elements=(1 << 28) + 1):
+    """Start-up check of the exchange path on the communicator at hand: every rank sends ONE message of `elements`
+    32-bit words (default 1 GiB + 4 bytes, above the size at which ROCm 7.2's RCCL was seen to lose the second half
+    of a 2 GiB self-send -- tools/rccl_selfcopy.py -- and above every message the sorter emits, MAX_MSG = 768 MiB) to
+    the next rank of a ring (to itself when there is one rank) and checks, on the device, that every word arrived.
+    Raises RuntimeError on a truncated or altered message, so that a sort never runs on a communicator that drops data.
+    Returns the number of words checked."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    nxt, prv = (rank + 1) % world, (rank - 1) % world
+    idx = torch.arange(elements, dtype=torch.int32, device=device)
+    src = idx * 747796405 + (rank + 1)                       # int32 wrap-around: a different stream per rank
+    dst = torch.zeros(elements, dtype=torch.int32, device=device)
+    send = [0] * world
+    recv = [0] * world
+    send[nxt] = elements
+    recv[prv] = elements
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        h = torch.empty(elements, dtype=torch.int32)
+        dist.all_to_all_single(h, src.cpu(), recv, send, group=group)
+        dst.copy_(h)
+    else:
+        dist.all_to_all_single(dst, src, recv, send, group=group)
+    expect = idx * 747796405 + (prv + 1)
+    bad = int((dst != expect).sum().item())
+    if bad:
+        first = int(torch.nonzero(dst != expect)[0].item())
+        raise RuntimeError(f"communicator self-test failed on rank {rank}: {bad} of {elements} words of a "
+                           f"{elements * 4} byte message from rank {prv} are wrong (first at word {first}): the "
+                           "collective library truncates or alters large messages on this machine")
+    return elements
 
 
 class ShardedSorter:

@@ -26,6 +26,8 @@ extern "C" {
 #endif
 
 #define GS_SHARDED_IMBALANCED 2001
+#define GS_SHARDED_PEER_FAILED 2002   /* another rank reported a local failure before the exchange; no data was moved */
+#define GS_SHARDED_TRUNCATED   2003   /* gs_sharded_selftest: the communicator lost or altered part of a large message */
 
 /* workspace for a rank that holds num_items keys and may receive up to `capacity` */
 size_t gs_msb_sharded_temp_bytes(uint64_t num_items, uint64_t capacity, int has_values, int world);
@@ -38,6 +40,27 @@ int gs_msb_sort_u32_sharded(void *d_temp, size_t temp_bytes, const uint32_t *d_k
                             uint32_t *d_recv_keys, uint32_t *d_recv_vals, uint32_t *d_keys_out, uint32_t *d_vals_out,
                             uint64_t capacity, uint64_t *num_out, void *nccl_comm, int rank, int world, int key_type,
                             void *stream);
+
+/* Error behaviour of gs_msb_sort_u32_sharded.  A rank whose first pass fails LOCALLY still takes part in the size
+ * all-gather (with a marker instead of sizes), so every rank returns -- the failing one with its error, the others with
+ * GS_SHARDED_PEER_FAILED -- and nobody is left waiting in a collective.  A failure INSIDE the exchange (ncclSend /
+ * ncclRecv / ncclGroupEnd) always closes the group it opened, then aborts the communicator (ncclCommAbort: the
+ * handle is dead afterwards) so that the peers' pending operations end instead of waiting for this rank for ever.   */
+
+/* The exchange plan of one rank, a pure host function of the gathered sizes (exposed for tests; every rank runs it on
+ * the same `counts` and `dest`): send_off[world + 1] = where rank r's slice of MY grouped shard starts (element
+ * offsets), recv_off[world + 1] = where source r's piece starts in MY receive buffer, pieces[world][256] = what
+ * source r sends me per top byte (gs_msb_finish_u32's piece table), *rounds = how many <= 768 MiB rounds the largest
+ * (source, destination) message of the whole exchange needs -- the same number on every rank.                        */
+void gs_sharded_exchange_plan(const uint64_t *counts, const uint8_t *dest_of_bucket, int rank, int world,
+                              uint64_t *send_off, uint64_t *recv_off, uint64_t *pieces, uint64_t *rounds);
+
+/* Start-up check of a communicator: every rank sends ONE message of `elements` 32-bit words (use 2^28 + 1: 1 GiB + 4
+ * bytes, above every message the sort emits) to the next rank of a ring (to itself when world == 1) and compares what
+ * arrived word for word.  Returns 0, a hipError_t / 1000 + ncclResult_t value, or GS_SHARDED_TRUNCATED.  RCCL of ROCm
+ * 7.2 was seen to deliver only the first half of a >= 2 GiB message to self; a machine on which this test fails must
+ * not run the sharded sort.                                                                                          */
+int gs_sharded_selftest(void *nccl_comm, int rank, int world, uint64_t elements, void *stream);
 
 /* the split every rank computes from the gathered sizes (exposed for tests): counts[world][256] -> dest_of_bucket[256],
  * per_rank[world]; bucket b goes to rank floor(world * keys_before_b / n), made monotone.                              */

@@ -123,7 +123,8 @@ def test_rccl_host_library_exports_and_split_rule(gs):
         pytest.skip("libgpusort_rccl.so not built (run __graft_entry__.build())")
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "gpusort_rccl.h")).read(), flags=re.S)
     syms = sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", text)))
-    assert syms == ["gs_msb_sharded_temp_bytes", "gs_msb_sort_u32_sharded", "gs_sharded_compute_splits"]
+    assert syms == ["gs_msb_sharded_temp_bytes", "gs_msb_sort_u32_sharded", "gs_sharded_compute_splits", "gs_sharded_exchange_plan",
+                    "gs_sharded_selftest"]
     lib = C.CDLL(path)
     for name in syms:
         assert hasattr(lib, name)
@@ -147,6 +148,61 @@ def test_rccl_host_library_exports_and_split_rule(gs):
             lib.gs_sharded_compute_splits(h.ctypes.data_as(C.c_void_p), world, dest.ctypes.data_as(C.c_void_p), per.ctypes.data_as(C.c_void_p))
             ed, ep = sharded.compute_splits(h, world)
             assert np.array_equal(dest, ed) and np.array_equal(per.astype(np.int64), ep), (world, kind)
+    # adversarial sizes: keys_before * world / n lands exactly ON an integer, or one key short of it, with totals beyond
+    # 2^53 / world (where a float64 quotient rounds the wrong way): both hosts use exact integers and must agree
+    def both(h, world):
+        dest = np.zeros(256, np.uint8)
+        per = np.zeros(world, np.uint64)
+        lib.gs_sharded_compute_splits(h.ctypes.data_as(C.c_void_p), world, dest.ctypes.data_as(C.c_void_p), per.ctypes.data_as(C.c_void_p))
+        ed, ep = sharded.compute_splits(h, world)
+        assert np.array_equal(dest, ed) and np.array_equal(per.astype(np.int64), ep), world
+        return dest
+    for world in (2, 3, 5, 7, 8):
+        for scale in (1, (1 << 40) + 1, (1 << 54) // (256 * world)):
+            for delta in (0, 1, -1):
+                h = np.zeros((world, 256), np.uint64)
+                h[0, :] = world * scale                 # every bucket boundary sits on an exact multiple of n / (256 * world) ...
+                if delta == 1:
+                    h[0, 0] += 1                        # ... or one key past it
+                if delta == -1:
+                    h[0, 0] -= 1                        # ... or one key short of it
+                    h[0, 255] += 1
+                d = both(h, world)
+                assert np.all(np.diff(d.astype(np.int64)) >= 0) and d[0] == 0 and d[-1] <= world - 1
+    # exact integer quotient (the float64 form this replaced gives 1 here): before * world / n = 1 - 2^-55
+    h = np.zeros((2, 256), np.uint64)
+    h[0, 0] = (1 << 54) - 1
+    h[0, 1] = 1
+    h[1, 2] = (1 << 54)
+    d = both(h, 2)
+    assert d[0] == 0 and d[1] == 0 and d[2] == 1                  # bucket 1 starts at (2^54 - 1) * 2 / 2^55 < 1 -> rank 0
+    # the exchange plan, a pure function: for every pair, what the sender cuts for the receiver is what the receiver
+    # expects from the sender, the pieces tile the receive buffer in source order, every rank derives the same rounds
+    lib.gs_sharded_exchange_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for world in range(2, 9):
+        h = rng.integers(0, 1 << 21, size=(world, 256)).astype(np.uint64)
+        h[world // 2, 40:60] *= 50
+        dest = both(h, world)
+        plans = []
+        for r in range(world):
+            so, ro = np.zeros(world + 1, np.uint64), np.zeros(world + 1, np.uint64)
+            pieces, rounds = np.zeros((world, 256), np.uint64), C.c_uint64(0)
+            lib.gs_sharded_exchange_plan(h.ctypes.data_as(C.c_void_p), dest.ctypes.data_as(C.c_void_p), r, world, so.ctypes.data_as(C.c_void_p),
+                                         ro.ctypes.data_as(C.c_void_p), pieces.ctypes.data_as(C.c_void_p), C.byref(rounds))
+            plans.append((so, ro, pieces, rounds.value))
+        assert len({pl[3] for pl in plans}) == 1 and plans[0][3] >= 1
+        for a in range(world):
+            so, ro, pieces, _ = plans[a]
+            assert so[0] == 0 and so[world] == h[a].sum() and np.all(np.diff(so.astype(np.int64)) >= 0)
+            es, er = sharded.exchange_plan(h, dest, a, world)             # the Python host's plan: same cuts
+            assert np.array_equal(np.diff(so.astype(np.int64)), es) and np.array_equal(np.diff(ro.astype(np.int64)), er)
+            for b in range(world):
+                sent = int(so[b + 1] - so[b])                                  # a -> b
+                assert sent == int(plans[b][1][a + 1] - plans[b][1][a])        # = what b expects from a
+                assert sent == int(plans[b][2][a].sum()) == int(h[a][dest == b].sum())
+            # my pieces: source-major, buckets in order inside a source, only buckets I own
+            assert np.array_equal(pieces, np.where(dest[None, :] == a, h, 0))
+            assert int(ro[world]) == int(pieces.sum())
     # argument validation happens before any GPU or RCCL call
     lib.gs_msb_sort_u32_sharded.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 2 + [C.c_uint64] + [C.c_void_p] * 6 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     n_out = C.c_uint64(0)
