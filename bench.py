@@ -12,6 +12,12 @@ step sorts its own pre-generated input buffer (seed = step index), so no restore
 the timed region (the reference restores inputs outside its timed call, lsb/sort.cu:141-146).
 
 Also reported on the same line:
+  verified     -- the LAST timed step's output checked on the device outside the timed region (sortedness + the
+                  multiset checksum of its input, taken before the sort)
+  also         -- N = 1, default workload only: BASELINE.json configs[2] (LSB pairs), configs[3] (MSB Zipf keys), MSB
+                  uniform keys and the one-rank rehearsal of configs[4]'s pipeline, 5 device-timed sorts each with a
+                  device-side check, after the headline's buffers are freed (the reference's drivers print both of their
+                  sorts in one run too, lsb/sort.cu:148-151, msb/src/test.cu:53-56).  `--no-also` skips it.
   roofline     -- the dominant kernel (lsb_downsweep): algorithmic bytes per launch
                   (8 B/key x keys per launch) / its average launch duration,
                   measured live with hipEvents on the launch stream during the timed steps.
@@ -42,6 +48,8 @@ def parse_args():
     ap.add_argument("--algo", choices=["lsb", "msb"], default=None)
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra configurations reported under `also`")
+    ap.add_argument("--also-steps", type=int, default=5)
     ap.add_argument("--cpu-sample-log2", type=int, default=27)
     ap.add_argument("--verify", action="store_true", help="device-side sortedness + checksum on every step")
     ap.add_argument("--exchange-groups", type=int, default=0,
@@ -113,6 +121,149 @@ def cpu_baseline(n_log2, pairs):
     return out
 
 
+def box_facts(torch, dev):
+    """What can differ between two boxes: clocks, partition modes, memory, allocator."""
+    out = {}
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        out.update(name=p.name, gcn_arch=getattr(p, "gcnArchName", None), cus=p.multi_processor_count,
+                   total_mem_GiB=round(p.total_memory / 2**30, 1), clock_mhz=getattr(p, "clock_rate", 0) // 1000 or None,
+                   memory_clock_mhz=getattr(p, "memory_clock_rate", 0) // 1000 or None, l2_MiB=round(getattr(p, "L2_cache_size", 0) / 2**20, 1))
+        free, total = torch.cuda.mem_get_info(dev)
+        out["free_mem_GiB"] = round(free / 2**30, 1)
+    except Exception as e:          # never let a diagnostic break the bench line
+        out["error"] = repr(e)
+    for key, path in (("compute_partition", "current_compute_partition"), ("memory_partition", "current_memory_partition")):
+        try:
+            import glob
+            vals = sorted({open(f).read().strip() for f in glob.glob(f"/sys/class/drm/card*/device/{path}")})
+            out[key] = vals[0] if len(vals) == 1 else vals
+        except Exception:
+            out[key] = None
+    out["allocator"] = "torch caching allocator (hipMalloc-backed, 2 MiB-aligned blocks for these sizes)"
+    return out
+
+
+def also_configs(gs, torch, dev, n, steps, log2n):
+    """BASELINE.json configs[2..4] next to the headline (N = 1): each workload sorted `steps` times from a restored
+    input, every sort bracketed by an event pair on its stream (median reported), the last result checked on the
+    device.  Returns {workload: {...}}."""
+    from gpu_sort_amd.msb import msb_census, msb_algorithmic_bytes
+    out = {}
+
+    def median_ms(fn, restore):
+        evs = []
+        for _ in range(steps + 1):                       # first one untimed (warm-up)
+            restore()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); res = fn(); b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        ms = sorted(x.elapsed_time(y) for x, y in evs[1:])
+        return ms[len(ms) // 2], ms[0], res
+
+    src = torch.empty(n, dtype=torch.int32, device=dev)
+    work = torch.empty(n, dtype=torch.int32, device=dev)
+    alt = torch.empty(n, dtype=torch.int32, device=dev)
+
+    # ---- configs[2]: LSB, (u32 key, u32 value) pairs
+    gs.generate_uniform_keys(n, seed=101, device=dev, out=src)
+    vals = torch.empty(n, dtype=torch.int32, device=dev)
+    vals_alt = torch.empty(n, dtype=torch.int32, device=dev)
+    nbytes = gs.lib.gs_lsb_temp_bytes(n, 1)
+    temp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    state = {}
+
+    def restore_pairs():
+        work.copy_(src)
+        gs.generate_enumerated_values(n, device=dev, out=vals)
+
+    def lsb_pairs():
+        dk, dv = gs.DoubleBuffer(work, alt), gs.DoubleBuffer(vals, vals_alt)
+        gs.DeviceRadixSort.SortPairs(temp, nbytes, dk, dv, n, key_type=gs.GS_KEY_U32)
+        return dk.Current(), dv.Current()
+
+    prof = gs.KernelProfile()
+    with prof:
+        med, mn, (rk, rv) = median_ms(lsb_pairs, restore_pairs)
+    k = prof.read()
+    inv = gs.check_sorted(rk)[0]
+    bad = gs.check_pairs_enumerated(src, rk, rv)[0]
+    ds_ms = k["lsb_downsweep"][0] / k["lsb_downsweep"][1]
+    gbs = 16 * n / (ds_ms * 1e-3) / 1e9
+    out[f"lsb_radix_sort_2^{log2n}_u32_uniform_pairs"] = {
+        "baseline_config": 2, "ms_device_median": round(med, 4), "ms_device_min": round(mn, 4), "rate": round(n / med / 1e6, 3), "unit": "Gpairs/s",
+        "whole_sort_frac_of_peak": round(LSB_BYTES_PER_KEY[True] * n / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "roofline": {"kernel": "lsb_downsweep", "algorithmic_bytes": 16 * n, "avg_launch_ms": round(ds_ms, 4), "achieved": round(gbs, 1),
+                     "frac": round(gbs / HBM_PEAK_GBS, 4)},
+        "verified": bool(inv == 0 and bad == 0), "check": "sorted on the device + every value still points at its key (gs_check_pairs_enumerated_u32)"}
+    del vals, vals_alt, temp
+
+    # ---- MSB: configs[3] (Zipf keys) and uniform keys
+    nbytes = gs.lib.gs_msb_temp_bytes(n, 0)
+    temp = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    for dist_name, gen, cfg in (("zipf", gs.generate_zipf_keys, 3), ("uniform", gs.generate_uniform_keys, None)):
+        gen(n, seed=102, device=dev, out=src)
+        pre = gs.check_sorted(src)[1:]
+
+        def restore():
+            work.copy_(src)
+
+        def msb():
+            return gs.rdxsrt_unstable_sort(work, None, n, alt, None, pre_allocated_dm=temp, synchronize=False).sorted_keys
+
+        prof = gs.KernelProfile()
+        with prof:
+            med, mn, res = median_ms(msb, restore)
+        k = prof.read()
+        invs, sm, xr = gs.check_sorted(res)
+        census = msb_census(temp, n, False)
+        by = msb_algorithmic_bytes(census, n, False)
+        per_sort = {g: k[g][0] / (steps + 1) for g in by if g in k}
+        dom = max(per_sort, key=per_sort.get)
+        gbs = by[dom] / (per_sort[dom] * 1e-3) / 1e9
+        tot = sum(by.values())
+        out[f"msb_radix_sort_2^{log2n}_u32_{dist_name}_keys_only"] = {
+            **({"baseline_config": cfg} if cfg else {}),
+            "ms_device_median": round(med, 4), "ms_device_min": round(mn, 4), "rate": round(n / med / 1e6, 3), "unit": "Gkeys/s",
+            "algorithmic_bytes_per_key": round(tot / n, 2), "whole_sort_frac_of_peak": round(tot / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": {"kernel": dom, "algorithmic_bytes": by[dom], "ms_per_sort": round(per_sort[dom], 4), "achieved": round(gbs, 1),
+                         "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "all_kernel_groups": {g: {"algorithmic_bytes": by[g], "ms_per_sort": round(per_sort[g], 4),
+                                                   "frac": round(by[g] / (per_sort[g] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for g in per_sort}},
+            "verified": bool(invs == 0 and (sm, xr) == pre), "check": "sorted on the device + multiset checksum of the input"}
+    del temp, alt
+
+    # ---- configs[4]'s pipeline on ONE rank (first digit pass -> [exchange: nothing to move] -> finish on the pieces):
+    # the like-for-like N = 1 point of the `--gpus N` curve
+    from gpu_sort_amd import sharded
+    gs.generate_uniform_keys(n, seed=103, device=dev, out=src)
+    runner = sharded.ShardedSorter(n, False, dev, pipeline="msb")
+    pre = runner.input_checksum(src)
+    state["res"] = None
+
+    def restore():
+        work.copy_(src)
+
+    def shard():
+        state["res"] = runner.sort(work, None)
+        return state["res"]
+
+    med, mn, (sk, _, cnt) = median_ms(shard, restore)
+    ok = runner.verify(sk, cnt, pre)[0]
+    runner.stage_times = {}
+    work.copy_(src)
+    runner.sort(work, None)
+    st = runner.stage_times
+    runner.stage_times = None
+    out[f"msb_sharded_one_rank_2^{log2n}_u32_uniform_keys_only"] = {
+        "baseline_config": 4, "note": "configs[4]'s pipeline (first pass + finish on received pieces, host-side split included) on one rank, no exchange",
+        "ms_device_median": round(med, 4), "ms_device_min": round(mn, 4), "rate": round(n / med / 1e6, 3), "unit": "Gkeys/s",
+        "stages_ms_serialised": {kk: round(float(v), 3) for kk, v in st.items()} if st else None,
+        "verified": bool(ok), "check": "slice sorted + multiset checksum of the input"}
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -170,6 +321,19 @@ def main():
         vals_alt = torch.empty(n, dtype=torch.int32, device=dev)
 
     sharded_path = world > 1 or args.force_sharded
+    comm_info = None
+    if dist.is_initialized():
+        # what the COMMUNICATOR says (not argv), and a start-up check that it delivers a 1 GiB + 4 byte message whole
+        from gpu_sort_amd import sharded as _sh
+        comm_info = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "rank0_device": str(dev)}
+        if not args.rehearse_on_one_gpu:
+            comm_info["selftest_words_per_rank"] = _sh.communicator_selftest(dev)      # MAX_MSG words; raises on a truncated message
+            try:        # informational: a message above the cap (the sorter never sends one)
+                _sh.communicator_selftest(dev, elements=(1 << 28) + 1)
+                comm_info["message_of_1GiB_plus_4B_whole"] = True
+            except RuntimeError:
+                comm_info["message_of_1GiB_plus_4B_whole"] = False
+            torch.cuda.empty_cache()
     if sharded_path:
         from gpu_sort_amd import sharded
         # default: exchange after the first MSB digit pass; --algo lsb|msb: group-by-destination + full local sort
@@ -186,6 +350,8 @@ def main():
         temp = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
 
     checks = []
+
+    last = {}
 
     def one_step(i):
         if sharded_path:
@@ -205,6 +371,7 @@ def main():
             seq = gs.rdxsrt_unstable_sort(inputs[i], vals[i] if args.pairs else None, n, alt, vals_alt,
                                           pre_allocated_dm=temp, synchronize=False)
             res = seq.sorted_keys
+        last["res"] = res
         if args.verify:
             checks.append(res)
 
@@ -213,6 +380,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    last_pre = None
+    if not sharded_path:
+        last_pre = gs.check_sorted(inputs[total - 1])[1:]     # multiset checksum of the LAST timed step's input
     pre = None
     if args.verify and not sharded_path:
         pre = [gs.check_sorted(inputs[i])[1:] for i in range(total)]
@@ -280,6 +450,10 @@ def main():
             stages = {k: round(float(v), 3) for k, v in zip(names, t.tolist())}
 
     verified = None
+    if not sharded_path and not args.verify:
+        # the last timed step's output, checked outside the timed region: sorted + same multiset as its input
+        inv, sm, xr = gs.check_sorted(last["res"])
+        verified = inv == 0 and (sm, xr) == last_pre
     if args.verify and not sharded_path:
         verified = True
         for j, res in enumerate(checks):
@@ -288,6 +462,13 @@ def main():
     elif args.verify:
         verified = all(checks)
 
+    if comm_info is not None and sharded_path and runner.last:
+        got = [None] * world
+        if world > 1:
+            dist.all_gather_object(got, int(runner.last["count"]))
+        else:
+            got = [int(runner.last["count"])]
+        comm_info["received_keys_per_rank_last_sort"] = got
     if rank == 0:
         keys_total = n * world * steps
         value = keys_total / elapsed / 1e9
@@ -334,6 +515,15 @@ def main():
             whole = {"algorithmic_bytes_per_key": LSB_BYTES_PER_KEY[args.pairs], "achieved_GBps": round(gbs, 1),
                      "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
                      "logical_GBps_cub_style": round(8 * n / (ms_per_step * 1e-3) / 1e9, 1)}
+        also = None
+        if (world == 1 and not sharded_path and algo == "lsb" and not args.pairs and args.dist == "uniform"
+                and not args.no_also and args.also_steps > 0):
+            inputs.clear()
+            last.clear()
+            checks.clear()
+            del alt, temp
+            torch.cuda.empty_cache()
+            also = also_configs(gs, torch, dev, n, args.also_steps, args.log2n)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(min(args.cpu_sample_log2, args.log2n), args.pairs)
@@ -353,8 +543,8 @@ def main():
                        "algorithm": ((f"shard_partition+local_{args.algo}" if args.algo else "msb_first_pass+all_to_all+msb_finish")
                                      if sharded_path else algo),
                        "distribution": args.dist, "parallelism": "single" if not sharded_path else f"msb_bucket_shard{world}"},
-            "stages_ms_serialised": stages,
-            "roofline": roofline, "whole_sort": whole, "cpu_baseline": cpu,
+            "stages_ms_serialised": stages, "rccl": comm_info,
+            "roofline": roofline, "whole_sort": whole, "cpu_baseline": cpu, "also": also, "box": box_facts(torch, dev),
             "kernels_ms_total": {k: [round(v[0], 3), v[1]] for k, v in kernels.items()},
         }
         if verified is not None:

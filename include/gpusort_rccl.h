@@ -55,11 +55,11 @@ int gs_msb_sort_u32_sharded(void *d_temp, size_t temp_bytes, const uint32_t *d_k
 void gs_sharded_exchange_plan(const uint64_t *counts, const uint8_t *dest_of_bucket, int rank, int world,
                               uint64_t *send_off, uint64_t *recv_off, uint64_t *pieces, uint64_t *rounds);
 
-/* Start-up check of a communicator: every rank sends ONE message of `elements` 32-bit words (use 2^28 + 1: 1 GiB + 4
- * bytes, above every message the sort emits) to the next rank of a ring (to itself when world == 1) and compares what
- * arrived word for word.  Returns 0, a hipError_t / 1000 + ncclResult_t value, or GS_SHARDED_TRUNCATED.  RCCL of ROCm
- * 7.2 was seen to deliver only the first half of a >= 2 GiB message to self; a machine on which this test fails must
- * not run the sharded sort.                                                                                          */
+/* Start-up check of a communicator: every rank sends ONE message of `elements` 32-bit words (use 3 << 26 = 768 MiB, the
+ * largest message the sort emits) to the next rank of a ring (to itself when world == 1) and compares what arrived
+ * word for word.  Returns 0, a hipError_t / 1000 + ncclResult_t value, or GS_SHARDED_TRUNCATED.  RCCL of ROCm 7.2 was
+ * seen to deliver only the first half of a self-send of 1 GiB + 4 bytes or more (1 GiB is whole): a machine on which
+ * this test fails at 768 MiB must not run the sharded sort.                                                          */
 int gs_sharded_selftest(void *nccl_comm, int rank, int world, uint64_t elements, void *stream);
 
 /* the split every rank computes from the gathered sizes (exposed for tests): counts[world][256] -> dest_of_bucket[256],

@@ -192,3 +192,34 @@ def test_compute_splits_properties():
 def test_tiny_shards(tmp_path, oracle, n, world, pipeline, groups):
     """a handful of keys per rank: most ranks receive nothing, most buckets and groups are empty"""
     test_sharded_sort_over_gloo(tmp_path, oracle, world, "zipf", True, pipeline, groups, None, n=n)
+
+
+def _selftest_worker(rank, world, port, elements, corrupt):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gpu_sort_amd import sharded
+    if corrupt:
+        # a collective that loses the second half of every message (what RCCL of ROCm 7.2 was seen to do to a
+        # >= 2 GiB self-send, tools/rccl_selfcopy.py): the self-test must notice
+        real = dist.all_to_all_single
+
+        def lossy(out, inp, recv, send, group=None):
+            real(out, inp, recv, send, group=group)
+            out[out.numel() // 2:] = 0
+        dist.all_to_all_single = lossy
+        with pytest.raises(RuntimeError, match="self-test failed"):
+            sharded.communicator_selftest(torch.device("cpu"), elements=elements)
+        dist.all_to_all_single = real
+    else:
+        assert sharded.communicator_selftest(torch.device("cpu"), elements=elements) == elements
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,corrupt", [(1, False), (2, False), (3, False), (2, True)])
+def test_communicator_selftest_over_gloo(world, corrupt):
+    """The start-up check bench.py runs on the real communicator (one big message around a ring, compared word for word):
+    passes on a working collective for 1, 2 and 3 ranks, raises on one that truncates."""
+    mp.spawn(_selftest_worker, args=(world, _free_port(), 100003, corrupt), nprocs=world, join=True)
