@@ -7,6 +7,7 @@
 // the global multiset unchanged).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -47,6 +48,9 @@ static int run_rank(int rank, int world, const std::string &id_file, int log2n, 
     CK(ncclCommInitRank(&comm, world, id, rank));
     hipStream_t s;
     CK(hipStreamCreate(&s));
+
+    // start-up check: the communicator delivers the sorter's largest message (768 MiB) whole (skipped for small runs)
+    if (log2n >= 28) CK(gs_sharded_selftest(comm, rank, world, 3ull << 26, s));
 
     const uint64_t n = 1ull << log2n, cap = n + n / 4 + 65536;
     uint32_t *kin, *grouped, *recv, *out, *vin = nullptr, *vgrouped = nullptr, *vrecv = nullptr, *vout = nullptr;
@@ -136,8 +140,35 @@ int main(int argc, char **argv)
             if (p == 0) _exit(run_rank(r, spawn, id_file, log2n, pairs, reps));
             kids.push_back(p);
         }
+        // Wait for ANY child.  As soon as one rank fails (or dies), its peers may be blocked in a collective that will
+        // never complete: give them a bounded time to return on their own (the host reports a peer's LOCAL failure through
+        // the size exchange, GS_SHARDED_PEER_FAILED), then end them, and exit non-zero -- the parent never waits for ever.
         int rc = 0;
-        for (pid_t p : kids) { int st = 0; waitpid(p, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st)) rc = 1; }
+        size_t left = kids.size();
+        auto reap = [&](pid_t p, int st) {
+            for (pid_t &k : kids)
+                if (k == p) { k = -1; --left; }
+            if (!WIFEXITED(st) || WEXITSTATUS(st)) rc = 1;
+        };
+        while (left && rc == 0) {
+            int st = 0;
+            const pid_t p = waitpid(-1, &st, 0);
+            if (p < 0) { rc = 1; break; }
+            reap(p, st);
+        }
+        if (left) {
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(20);
+            while (left && std::chrono::steady_clock::now() < deadline) {
+                int st = 0;
+                const pid_t p = waitpid(-1, &st, WNOHANG);
+                if (p > 0) reap(p, st);
+                else std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            }
+            for (pid_t k : kids)
+                if (k > 0) { std::fprintf(stderr, "msb_sharded: ending rank process %ld after a peer's failure\n", (long)k); kill(k, SIGKILL); }
+            for (pid_t k : kids)
+                if (k > 0) { int st = 0; waitpid(k, &st, 0); }
+        }
         std::remove(id_file.c_str());
         return rc;
     }
