@@ -689,182 +689,11 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
     }
 #endif
     if (!TAIL && blockIdx.x >= full_tiles) return;   // (n_ is preloaded: two scalar instructions, no memory wait)
-    const uint32_t t = TAIL ? full_tiles : (p.solo_tile_plus1 ? p.solo_tile_plus1 - 1u : tile_of_item(blockIdx.x, full_tiles));
+    const uint32_t t = TAIL ? full_tiles : tile_of_item(blockIdx.x, full_tiles);
     downsweep_tile<HAS_VALUES, TAIL, TW, BIG, false>(sm, t, keys_in, keys_out, vals_in, vals_out, spine, prefix16, totals, p,
                                                      nullptr, 0u, nullptr);
 }
 
-
-// ------------------------------------------------- downsweep, 16384-key tiles (keys only) --
-// What the scatter costs is its partial 128-byte lines (tools/micro/lsb_floor.hip, profiles/r03_lsb_floor.md): a tile of 8192
-// keys leaves runs of ~32 keys = 128 bytes per digit, so EVERY output line is written in two pieces by two workgroups; with
-// 16384 keys per tile the runs are ~256 bytes and half of the lines leave a workgroup whole.  Shape: 16 waves x 16 keys,
-// two workgroups per CU (32 waves, so <= 64 VGPRs: the ranks travel packed two to a register), 73 KiB of LDS: 64 KiB of
-// staging, the 16 x 256 wave-private counters as 16-bit halves of 32-bit words (a wave counts at most 1024 keys of a digit;
-// the group's first lane adds `size << 16 * (digit & 1)` to the word), 1 KiB of global bases.  Every wave computes its own
-// row of tile-absolute bases from the 16 rows (no serial section), writes it over its own counter row behind a barrier
-// (all rows have been read), and the rest is the 8192-key kernel's: LDS exchange in rank order, wave-contiguous stores.
-// The tile's global offsets come from the upsweep's 8192-key tiles: tile T of this kernel starts where tile 2T starts.
-constexpr int DS16_WAVES = 16;
-constexpr int DS16_THREADS = DS16_WAVES * WAVE;
-constexpr int DS16_TILE = DS16_THREADS * LSB_KPT;      // 16384 keys = 64 KiB
-
-struct Downsweep16Smem {
-    uint32_t cnt[DS16_WAVES][RADIX / 2];     // [wave][digit / 2]: counts of digits 2k (low half) and 2k + 1 (high half); then the wave's bases
-    uint32_t gbase[RADIX];
-    uint32_t stage[DS16_TILE];
-};
-typedef uint16_t __attribute__((may_alias)) u16_alias;
-
-template <int TW, bool BIG>
-__global__ __launch_bounds__(DS16_THREADS, 8) void lsb_downsweep16_kernel(
-    const uint32_t n_, const uint32_t shift_, const uint32_t bits_, const uint32_t grid_,
-    const uint32_t *__restrict__ keys_in, uint32_t *__restrict__ keys_out, const uint32_t *__restrict__ totals,
-    const uint32_t *__restrict__ spine, const uint16_t *__restrict__ prefix16, PassParams p)
-{
-    __shared__ __attribute__((aligned(16))) Downsweep16Smem sm;
-    const uint32_t full16 = n_ / (uint32_t)DS16_TILE;
-    if (blockIdx.x >= full16) return;
-    const uint32_t t = tile_of_item(blockIdx.x, full16);
-    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    auto tw_in = [&](uint32_t k) { return TW == 0 ? k : twiddle_in(k, TW == 2 ? p.f32_in : 0, p.xor_in); };
-    auto tw_out = [&](uint32_t k) { return TW == 0 ? k : twiddle_out(k, TW == 2 ? p.f32_out : 0, p.xor_out); };
-    uint32_t wbits = bits_;
-    asm volatile("" : "+v"(wbits));
-    auto digit = [&](uint32_t k) { return __builtin_amdgcn_ubfe(k, shift_, wbits); };
-
-    // wave 0 requests the digit totals and this tile's offsets first (six loads), then every wave its keys; wave 0 parks
-    // its sums in `gbase` as soon as they are back (the keys are still on their way: vmcnt counts in order) -- it has no
-    // registers to carry them through the ranking
-    uint4 tot = make_uint4(0, 0, 0, 0);
-    uint2 pf = make_uint2(0, 0);
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (w == 0) {
-        const uint32_t t8 = t * (uint32_t)(DS16_TILE / LSB_TILE);
-        const uint32_t *sp = spine + t8 / LSB_CHUNK;            // scalar base, 32-bit vector index
-        const uint32_t at = 4u * lane * grid_;
-        tot = reinterpret_cast<const uint4 *>(totals)[lane];
-        pf = reinterpret_cast<const uint2 *>(prefix16 + (size_t)t8 * RADIX)[lane];
-        s0 = sp[at]; s1 = sp[at + grid_]; s2 = sp[at + 2u * grid_]; s3 = sp[at + 3u * grid_];
-    }
-    // 1. wave-striped coalesced load (position order = (wave, round, lane))
-    __builtin_amdgcn_s_setprio(3);
-    uint32_t key[LSB_KPT];
-    {
-        const uint32_t *kin = keys_in + (size_t)t * DS16_TILE;   // scalar base
-        const uint32_t at = w * (WAVE * LSB_KPT) + lane;
-#pragma unroll
-        for (int i = 0; i < LSB_KPT; ++i) key[i] = kin[at + i * WAVE];
-    }
-    __builtin_amdgcn_s_setprio(0);
-    if (w == 0) {   // lane l: global start of digits 4l .. 4l + 3 + this tile's offset in them
-        const uint32_t lane_sum = tot.x + tot.y + tot.z + tot.w;
-        const uint32_t d0 = wave_inclusive_scan(lane_sum) - lane_sum, d1 = d0 + tot.x, d2 = d1 + tot.y, d3 = d2 + tot.z;
-        reinterpret_cast<uint4 *>(sm.gbase)[lane] =
-            make_uint4(d0 + s0 + (pf.x & 0xffffu), d1 + s1 + (pf.x >> 16), d2 + s2 + (pf.y & 0xffffu), d3 + s3 + (pf.y >> 16));
-    }
-    uint32_t *my = sm.cnt[w];
-    reinterpret_cast<uint2 *>(my)[lane] = make_uint2(0u, 0u);
-
-    // 2. rank inside the wave: ballot match -> rank inside the group; the wave's running count of the digit -> rank of the
-    //    group (read one round later, so the LDS latency hides behind the next match).  Ranks packed two to a register.
-#pragma unroll
-    for (int i = 0; i < LSB_KPT; ++i) key[i] = tw_in(key[i]);
-    uint32_t posp[LSB_KPT / 2];
-    {
-        uint32_t word_prev = 0, sh_prev = 0, lower_prev = 0;
-#pragma unroll
-        for (int i = 0; i <= LSB_KPT; ++i) {
-            uint32_t lo = 0, hi = 0, d = 0;
-            if (i < LSB_KPT) {
-                d = digit(key[i]);
-                match_digit(d, lo, hi);
-            }
-            if (i > 0) {   // round i - 1's count has had a whole match to come back
-                const uint32_t pos = __builtin_amdgcn_ubfe(word_prev, sh_prev, 16) + lower_prev;
-                if ((i - 1) & 1) posp[(i - 1) >> 1] |= pos << 16;
-                else posp[(i - 1) >> 1] = pos;
-                asm volatile("" : "+v"(posp[(i - 1) >> 1]));      // computed HERE (left to itself the compiler sinks all 16 to the end of the loop,
-                                                                  // keeping three registers per round alive)
-            }
-            if (i < LSB_KPT) {
-                const uint32_t lower = count_lower(lo, hi);
-                uint32_t *word = my + (d >> 1);
-                const uint32_t sh = (d & 1u) << 4;
-                word_prev = *word;                                                  // LDS read, all lanes
-                if (lower == 0)                                                     // first lane of the group adds the group size
-                    __hip_atomic_fetch_add(word, (uint32_t)(__popc(lo) + __popc(hi)) << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                sh_prev = sh; lower_prev = lower;
-            }
-            __builtin_amdgcn_sched_barrier(0);      // one round at a time: nothing of a later round is hoisted into registers
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < LSB_KPT; ++i) asm volatile("" : "+v"(key[i]));
-#pragma unroll
-    for (int i = 0; i < LSB_KPT / 2; ++i) asm volatile("" : "+v"(posp[i]));
-    __syncthreads();
-
-    // 3. every wave: the 16 rows -> digit totals and the counts of the waves below it (two 16-bit sums per register: a tile
-    //    holds at most 16384 keys of a digit... exactly 16384 only if ALL keys share it, which still fits 16 bits minus
-    //    nothing: 16384 < 65536), scan of the 256 totals, own bases = tile start of the digit + counts below.
-    uint32_t b01, b23;
-    {
-        uint32_t run01 = 0, run23 = 0, below01 = 0, below23 = 0;
-        const uint32_t ws = __builtin_amdgcn_readfirstlane(w);
-#pragma unroll
-        for (int j = 0; j < DS16_WAVES; j += 4) {          // four rows in flight at a time (all sixteen would cost 32 registers)
-            uint2 x[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = reinterpret_cast<const uint2 *>(sm.cnt[j + u])[lane];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t m = (uint32_t)(j + u) < ws ? 0xffffffffu : 0u;      // scalar: rows of the waves below mine
-                below01 += x[u].x & m; below23 += x[u].y & m;
-                run01 += x[u].x; run23 += x[u].y;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const uint32_t c0 = run01 & 0xffffu, c1 = run01 >> 16, c2 = run23 & 0xffffu, c3 = run23 >> 16;
-        const uint32_t lane_sum = c0 + c1 + c2 + c3;
-        const uint32_t e0 = wave_inclusive_scan(lane_sum) - lane_sum, e1 = e0 + c0, e2 = e1 + c1, e3 = e2 + c2;
-        b01 = (e0 | (e1 << 16)) + below01;          // every base < 16384: no carry between the halves
-        b23 = (e2 | (e3 << 16)) + below23;
-        if (w == 0) {   // global base of a digit run = digit start + tile offset - tile-local start
-            uint4 g = reinterpret_cast<const uint4 *>(sm.gbase)[lane];
-            g.x -= e0; g.y -= e1; g.z -= e2; g.w -= e3;
-            if (!BIG) { g.x <<= 2; g.y <<= 2; g.z <<= 2; g.w <<= 2; }       // byte offsets (mod 2^32; exact once the slot is added)
-            reinterpret_cast<uint4 *>(sm.gbase)[lane] = g;
-        }
-    }
-    __syncthreads();                                 // all rows read: each wave's row now takes its bases
-    reinterpret_cast<uint2 *>(my)[lane] = make_uint2(b01, b23);
-    asm volatile("" ::: "memory");
-
-    // 4. tile -> LDS in rank order (all 16 base reads issued before the first write)
-    {
-        const u16_alias *mybase = reinterpret_cast<const u16_alias *>(my);
-        uint32_t wb[LSB_KPT];
-#pragma unroll
-        for (int i = 0; i < LSB_KPT; ++i) wb[i] = mybase[digit(key[i])];
-#pragma unroll
-        for (int i = 0; i < LSB_KPT; ++i) {
-            const uint32_t pos = (i & 1) ? (posp[i >> 1] >> 16) : (posp[i >> 1] & 0xffffu);
-            sm.stage[pos + wb[i]] = key[i];
-        }
-    }
-    __syncthreads();
-    // 5. global: a wave stores 1024 consecutive rank slots (see the 8192-key kernel)
-    __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-    for (int i = 0; i < LSB_KPT; ++i) {
-        const uint32_t slot = w * (WAVE * LSB_KPT) + i * WAVE + lane;
-        const uint32_t k = sm.stage[slot];
-        const uint32_t g = sm.gbase[digit(k)];
-        if (BIG) keys_out[g + slot] = tw_out(k);
-        else *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(keys_out) + (g + slot * 4u)) = tw_out(k);
-    }
-}
 
 // ---------------------------------------------------------- pipelined pass --
 // One launch = one pass, the north_star's three steps as ROLES of its workgroups:
@@ -1169,24 +998,6 @@ static void launch_downsweep_tail(const uint32_t *kin, uint32_t *kout, const uin
                            totals, (const uint32_t *)nullptr, (const uint16_t *)nullptr, vin, vout, p);
 }
 
-// Keys only, arrays of at least DS16_MIN_KEYS: the full 16384-key tiles go through lsb_downsweep16_kernel, an odd last
-// 8192-key tile through the 8192-key kernel launched for that one tile.  GS_LSB_TILE16=0 switches the wide tiles off
-// (A/B measurements; read once per process).
-constexpr uint64_t DS16_MIN_KEYS = 1ull << 25;
-static inline bool ds16_enabled()
-{
-    static const bool on = [] { const char *e = getenv("GS_LSB_TILE16"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
-template <int TW, bool BIG>
-static void launch_downsweep16(const uint32_t *kin, uint32_t *kout, const uint32_t *spine, const uint16_t *prefix16,
-                               const uint32_t *totals, const PassParams &p, hipStream_t s)
-{
-    hipLaunchKernelGGL((lsb_downsweep16_kernel<TW, BIG>), dim3(p.n / (uint32_t)DS16_TILE), dim3(DS16_THREADS), 0, s, p.n, p.shift, p.bits,
-                       p.grid, kin, kout, totals, spine, prefix16, p);
-}
-
 int lsb_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, const uint32_t *spine,
                   const uint16_t *prefix16, const uint32_t *totals, const PassParams &p, hipStream_t s)
 {
@@ -1194,24 +1005,10 @@ int lsb_downsweep(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint
     if (p.n >= (uint32_t)LSB_TILE) {   // full tiles
         const int tw = (p.f32_in || p.f32_out) ? 2 : ((p.xor_in | p.xor_out) ? 1 : 0);
         const bool big = p.n > (1u << 30);
-        if (!vin && p.n >= DS16_MIN_KEYS && ds16_enabled()) {
-#define GS_DS16(TW_, BIG_) launch_downsweep16<TW_, BIG_>(kin, kout, spine, prefix16, totals, p, s)
-            if (big) { if (tw == 2) GS_DS16(2, true); else if (tw == 1) GS_DS16(1, true); else GS_DS16(0, true); }
-            else { if (tw == 2) GS_DS16(2, false); else if (tw == 1) GS_DS16(1, false); else GS_DS16(0, false); }
-#undef GS_DS16
-            const uint32_t full8 = p.n / (uint32_t)LSB_TILE;
-            if (full8 & 1u) {          // the 8192-key tile behind the last 16384-key tile
-                PassParams q = p;
-                q.solo_tile_plus1 = full8;     // tile index full8 - 1
-                hipLaunchKernelGGL((lsb_downsweep_kernel<false, false, 2, true>), dim3(1), dim3(LSB_THREADS), 0, s, q.n, q.shift, q.bits, q.grid,
-                                   kin, kout, totals, spine, prefix16, vin, vout, q);
-            }
-        } else {
 #define GS_DS(TW_, BIG_) launch_downsweep<TW_, BIG_>(kin, kout, vin, vout, spine, prefix16, totals, p, s)
-            if (big) { if (tw == 2) GS_DS(2, true); else if (tw == 1) GS_DS(1, true); else GS_DS(0, true); }
-            else { if (tw == 2) GS_DS(2, false); else if (tw == 1) GS_DS(1, false); else GS_DS(0, false); }
+        if (big) { if (tw == 2) GS_DS(2, true); else if (tw == 1) GS_DS(1, true); else GS_DS(0, true); }
+        else { if (tw == 2) GS_DS(2, false); else if (tw == 1) GS_DS(1, false); else GS_DS(0, false); }
 #undef GS_DS
-        }
     }
     if (p.n % (uint32_t)LSB_TILE) launch_downsweep_tail(kin, kout, vin, vout, totals, p, s);   // the partial last tile
     return (int)hipGetLastError();

@@ -31,7 +31,6 @@ struct PassParams {
     uint32_t mask;
     int f32_in, f32_out;          // float twiddle on read / undo on write
     uint32_t xor_in, xor_out;     // uniform xor on read / write (sign flip, descending)
-    uint32_t solo_tile_plus1;     // downsweep launched for ONE full tile (index + 1; 0 = the usual grid over all full tiles)
 };
 
 // Block i -> tile.  Blocks are dispatched in order, so the resident blocks work on
