@@ -129,6 +129,33 @@ __device__ __forceinline__ void upsweep_chunk(UpsweepSmem<NEXT, PIPE> &sm, const
         }
     }
     __syncthreads();
+#if defined(GS_EXP_UPS) && GS_EXP_UPS >= 1
+    // timing experiments only (results land in the wrong layout): 1 = the chunk's prefix16 rows as ONE 16-byte store per
+    // digit thread (4 KiB per workgroup in four wave instructions instead of 32), 2 = also the spine as one 1 KiB row per
+    // chunk, 3 = no result stores at all
+    if (!PIPE && !NEXT && tid < RADIX) {
+        uint32_t run = 0, pk[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < LSB_WAVES; ++j) {
+            pk[j >> 1] |= (run & 0xffffu) << (16 * (j & 1));
+            uint32_t c = 0;
+#pragma unroll
+            for (int u = 0; u < UPSWEEP_SUB; ++u) c += sm.hist[j][u][tid];
+            run += c;
+        }
+#if GS_EXP_UPS < 3
+        reinterpret_cast<uint4 *>(prefix16 + (size_t)chunk * LSB_CHUNK * RADIX)[tid] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+#if GS_EXP_UPS == 2
+        spine[(size_t)chunk * RADIX + tid] = run;
+#else
+        spine[(uint32_t)tid * p.grid + chunk] = run;
+#endif
+#else
+        if (run == 0xffffffffu) spine[0] = pk[0] + pk[1] + pk[2] + pk[3];
+#endif
+        return;
+    }
+#endif
     if (tid < RADIX) {
         uint32_t run = 0;
 #pragma unroll
