@@ -45,6 +45,7 @@ SIGNATURES = {
     "gs_msb_wide_temp_bytes": (sz, [u64, i32, i32]),
     "gs_msb_sort_wide": (i32, [vp, sz, vp, vp, u64, vp, vp, i32, i32, pp, pp, i32, vp, i32]),
     "gs_msb_census": (i32, [vp, u64, i32, vp, vp]),
+    "gs_msb_capacities": (None, [u64, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gs_msb_classify_upto": (i32, [vp, sz, vp, vp, u64, i32, i32, vp]),
     "gs_msb_read_lists": (i32, [vp, u64, i32, i32, vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint32)), C.c_uint32,
                                 C.POINTER(C.c_uint32), vp]),

@@ -335,6 +335,7 @@ struct DownsweepSmem {
 #endif
     uint32_t gbase[RADIX];                                // global offset of digit run - tile-local start
     uint32_t stage[LSB_TILE * (HAS_VALUES ? 2 : 1)];      // tile in rank order; pairs interleaved {key,val}
+    uint32_t dead;                                        // pipelined pass only: wave 0's wait gave up -> the tile stores nothing
 };
 
 #ifdef GS_EXP_PHASES
@@ -474,20 +475,25 @@ __device__ __forceinline__ void downsweep_tile(DownsweepSmem<HAS_VALUES> &sm, co
     if (PIPE && !TAIL && w == 0) {
         // every granule carries this pass's tag once the scanner has written it (normally long ago: the upsweep
         // role runs PIPE_LEAD_CHUNKS ahead); only then may the prefix16 row be read (it was published before the
-        // counts the scanner waited for).  Bounded: a wait that gives up flags the sort instead of hanging the GPU.
+        // counts the scanner waited for).  Bounded: a wait that gives up flags the sort instead of hanging the GPU --
+        // and the tile then stores NOTHING: its offsets would come from untagged words (stale values of another pass
+        // can exceed n: an out-of-bounds scatter), so the whole workgroup leaves behind the first barrier.
         uint32_t spins = 0;
+        bool gave_up = false;
         for (;;) {
             const bool ok = (uint32_t)(scg[0] >> 32) == tag && (uint32_t)(scg[1] >> 32) == tag &&
                             (uint32_t)(scg[2] >> 32) == tag && (uint32_t)(scg[3] >> 32) == tag;
             if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
             if (++spins > PIPE_SPIN_LIMIT) {
                 if (lane == 0) atomicOr(error_word, 1u);
+                gave_up = true;
                 break;
             }
             __builtin_amdgcn_s_sleep(8);
 #pragma unroll
             for (int q = 0; q < 4; ++q) scg[q] = ld_agent(scrow + q);
         }
+        if (lane == 0) sm.dead = gave_up ? 1u : 0u;
         const uint64_t pf = ld_agent(reinterpret_cast<const uint64_t *>(prefix16 + (size_t)t * RADIX) + lane);
         tbase[0] = (uint32_t)scg[0] + (uint32_t)(pf & 0xffffu);
         tbase[1] = (uint32_t)scg[1] + (uint32_t)((pf >> 16) & 0xffffu);
@@ -555,6 +561,7 @@ __device__ __forceinline__ void downsweep_tile(DownsweepSmem<HAS_VALUES> &sm, co
     GS_PHASE(2);                                   // rank
     __syncthreads();
     GS_PHASE(3);                                   // barrier 1
+    if (PIPE && !TAIL && sm.dead) return;          // the wait for this tile's offsets gave up: no global store (all waves alike)
 
     // 3. wave histograms -> tile-absolute base of every (wave, digit) + global base per digit.
     //    4 digits per lane, b128 LDS accesses, DPP scan of the 256 digit totals.
@@ -779,7 +786,10 @@ __device__ __forceinline__ void pipe_scan_rows(uint32_t slice, const uint32_t *_
             v[k] = ld_agent(reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(cc) + (off + (uint32_t)k * RADIX * 4u)));
     };
     uint32_t run = 0;
-    auto consume = [&](uint32_t (&v)[K], uint32_t b) {
+    // returns false when the wait for a batch gave up: the scanner then publishes NOTHING more (rows tagged as valid but
+    // summed from untagged counts would be trusted by every tile behind them); the tiles that depend on the missing
+    // rows time out in turn and store nothing
+    auto consume = [&](uint32_t (&v)[K], uint32_t b) -> bool {
         uint32_t spins = 0;
         for (;;) {
             bool bad = false;
@@ -788,7 +798,7 @@ __device__ __forceinline__ void pipe_scan_rows(uint32_t slice, const uint32_t *_
             if (__builtin_amdgcn_ballot_w64(bad) == 0) break;
             if (++spins > PIPE_SPIN_LIMIT) {
                 if (lane == 0) atomicOr(error_word, 2u);
-                break;
+                return false;
             }
             __builtin_amdgcn_s_sleep(8);
             request(v, b);
@@ -806,6 +816,7 @@ __device__ __forceinline__ void pipe_scan_rows(uint32_t slice, const uint32_t *_
                      ((uint64_t)tag << 32) | (uint64_t)acc);
             acc += v[k];
         }
+        return true;
     };
     static_assert(A == 3, "the ring below is written out for three batches ahead");
     uint32_t v0[K], v1[K], v2[K], v3[K];
@@ -815,16 +826,16 @@ __device__ __forceinline__ void pipe_scan_rows(uint32_t slice, const uint32_t *_
 #pragma unroll 1
     for (uint32_t b = 0; b < nb; b += 4) {
         if (b + 3 < nb) request(v3, b + 3);
-        consume(v0, b);
+        if (!consume(v0, b)) return;
         if (b + 1 >= nb) break;
         if (b + 4 < nb) request(v0, b + 4);
-        consume(v1, b + 1);
+        if (!consume(v1, b + 1)) return;
         if (b + 2 >= nb) break;
         if (b + 5 < nb) request(v1, b + 5);
-        consume(v2, b + 2);
+        if (!consume(v2, b + 2)) return;
         if (b + 3 >= nb) break;
         if (b + 6 < nb) request(v2, b + 6);
-        consume(v3, b + 3);
+        if (!consume(v3, b + 3)) return;
     }
 }
 
@@ -870,6 +881,7 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_pipe_pass
             st_agent(reinterpret_cast<uint64_t *>(cc + (size_t)chunk * RADIX) + threadIdx.x, ((uint64_t)(q.tag << 28) << 32) | (q.tag << 28));
         return;
     }
+    if (chunk + 1u == q.test_drop_chunk_plus1) return;       // test hook: this chunk's counts are never published
     if (q.next_bits) upsweep_chunk<true, true>(sm.us, keys_in, chunk, nullptr, prefix16, cc, next_totals, p, q);
     else upsweep_chunk<false, true>(sm.us1, keys_in, chunk, nullptr, prefix16, cc, next_totals, p, q);
 }
@@ -1100,6 +1112,7 @@ static int lsb_run_passes(const LsbWorkspace &ws, uint64_t num_items, int begin_
             q.tag = (uint32_t)pass + 1u;
             q.lead_chunks = PIPE_LEAD_CHUNKS;
             q.scan_rows = (p.grid + PIPE_ROW_PAD - 1u) / PIPE_ROW_PAD * PIPE_ROW_PAD;   // whole scanner batches (<= grid + pad - 1)
+            if (const char *e = getenv("GS_LSB_PIPE_TEST_DROP")) q.test_drop_chunk_plus1 = (uint32_t)strtoul(e, nullptr, 10) + 1u;   // test hook
             if (pass + 1 < num_passes) {
                 q.next_shift = (uint32_t)(shift + RADIX_BITS);
                 q.next_bits = (uint32_t)((end_bit - (int)q.next_shift < RADIX_BITS) ? end_bit - (int)q.next_shift : RADIX_BITS);

@@ -63,6 +63,8 @@ struct PipeParams {
     uint32_t lead_chunks;          // upsweep blocks dispatched before the first downsweep block (multiple of 8)
     uint32_t scan_rows;            // rows the scanner walks: the chunks, rounded up to whole scanner batches
     uint32_t next_shift, next_bits;   // digit of the NEXT pass, whose totals the upsweep gathers on the way (0 bits: none)
+    uint32_t test_drop_chunk_plus1;   // test hook (GS_LSB_PIPE_TEST_DROP): the upsweep role of this chunk (+ 1) publishes nothing,
+                                      // so the waits behind it give up -- tests/test_lsb_gpu.py::test_one_launch_pass_give_up_stores_nothing
 };
 constexpr uint32_t PIPE_LEAD_CHUNKS = 128;   // 1024 tiles = 32 MiB of keys ahead (re-read window of the Infinity Cache: < 2048 tiles)
 constexpr uint32_t PIPE_SUB_BLOCKS = 72;     // 8 upsweep blocks (chunks) followed by the 64 downsweep blocks of 64 tiles

@@ -82,7 +82,9 @@ struct MsbLevel {
     uint32_t task_count[MSB_NCLASS];     // local-sort tasks emitted by this level's classification
     uint32_t flagged;                    // != 0: the one-pass local sort left tasks to the general kernel (a plain store:
                                          // thousands of atomics on one word would cost a millisecond)
-    uint32_t unused0;
+    uint32_t overflow;                   // level 0's record only: != 0 once ANY device-side append of the sort was clamped by a list
+                                         // capacity (a bucket, tile or task record dropped: the result is then wrong).  "Never by
+                                         // sizing" (msb_max_*) is an argument; this word is the check.
     unsigned long long unused1;
     unsigned long long keys;             // level 0: the array's size (census)
     unsigned long long unused2;
@@ -91,6 +93,7 @@ struct MsbLevel {
 // Census (gs_msb_census: what bench.py prices the MSB sort's algorithmic bytes with).  Every classification block sums what
 // its buckets pass on and leaves ONE record; the reader adds them up.  (Three or four global atomics per bucket on the
 // level's counters were half of the classification's time once a level had thousands of buckets: Zipf 2^30, 0.46 -> 0.25 ms.)
+#define MSB_OVERFLOW(ws_) ((ws_).level[0].overflow = 1u)      /* plain store, idempotent; see MsbLevel::overflow */
 struct MsbCensusSlot { unsigned long long next_keys, task_keys, pivot_keys, pivot_buckets; };
 constexpr uint32_t MSB_CLASSIFY_GRID = 4096;   // classification blocks per launch at most = census slots per level
 // Heavy hitters (skewed inputs: BASELINE configs[3], Zipf).  A bucket in which ONE key value holds at least half of the
@@ -180,6 +183,12 @@ static MsbWs msb_carve(void *temp, uint64_t n, bool has_values, uint32_t extra =
     const uint32_t tile = wide_cap ? 4096u : (uint32_t)MSB_TILE;
     ws.max_buckets = msb_max_buckets(n, has_values, extra, wide_cap);
     ws.max_tasks = msb_max_tasks(n, has_values, extra, extra_tasks, wide_cap);
+    // test hook (tests/test_msb_gpu.py::test_list_overflow_is_reported): a smaller task-list bound than the sizing gives,
+    // so that the overflow path can be exercised at all.  Read on every call; never set in production.
+    if (const char *e = getenv("GS_MSB_TEST_MAX_TASKS")) {
+        const uint32_t lim = (uint32_t)strtoul(e, nullptr, 10);
+        if (lim >= 1u && lim < ws.max_tasks) ws.max_tasks = lim;
+    }
     ws.max_tiles = msb_max_tiles(n, has_values, extra, wide_cap, tile);
     ws.stride = ws.max_tiles / MSB_WAVES;
     ws.tile_shift = wide_cap ? 12u : 13u;
@@ -225,7 +234,7 @@ __global__ void msb_single_task_kernel(MsbWs ws, uint32_t n, int cls)
 __global__ __launch_bounds__(256) void msb_expand_kernel(MsbWs ws, int L, const uint32_t *__restrict__ pivot_src = nullptr)
 {
     uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
-    if (nb > ws.max_buckets) nb = ws.max_buckets;
+    if (nb > ws.max_buckets) { nb = ws.max_buckets; MSB_OVERFLOW(ws); }
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const MsbBucket B = ws.buckets[L & 1][b];
         if (pivot_src && threadIdx.x < WAVE) {
@@ -245,6 +254,7 @@ __global__ __launch_bounds__(256) void msb_expand_kernel(MsbWs ws, int L, const 
             const uint32_t lo = B.offset + t * tl, left = B.size - t * tl;
             if (B.tile_start + t < ws.max_tiles)
                 ws.tiles[B.tile_start + t] = MsbTile{lo, left < tl ? left : tl, b, 0u};
+            else MSB_OVERFLOW(ws);
         }
     }
 }
@@ -260,6 +270,7 @@ __global__ __launch_bounds__(256) void msb_expand_pieces_kernel(MsbWs ws, uint32
             const uint32_t left = P.size - t * MSB_TILE;
             if (P.tile_start + t < ws.max_tiles)
                 ws.tiles[P.tile_start + t] = MsbTile{P.lo + t * MSB_TILE, left < (uint32_t)MSB_TILE ? left : (uint32_t)MSB_TILE, P.bucket, 0u};
+            else MSB_OVERFLOW(ws);
         }
     }
 }
@@ -433,7 +444,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
     __shared__ uint32_t s_p[RADIX], s_ln[RADIX], s_rank2idx[RADIX], s_mark[RADIX], s_jump[2][RADIX];   // the merge (see below)
     __shared__ unsigned long long s_base64;
     uint32_t nb = (uint32_t)(ws.level[L].packed >> 32);
-    if (nb > ws.max_buckets) nb = ws.max_buckets;              // never (see MsbWs)
+    if (nb > ws.max_buckets) { nb = ws.max_buckets; MSB_OVERFLOW(ws); }   // never (see MsbWs)
     const int d = threadIdx.x;
     MsbCensusSlot acc{0ull, 0ull, 0ull, 0ull};                   // thread 0's running census of this block's buckets
     CLS_STAMP(0);
@@ -471,6 +482,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
                         while (ws.caps[cls] < sizes[q]) ++cls;
                         const uint32_t at = atomicAdd(&ws.level[L].task_count[cls], 1u);
                         if (at < ws.max_tasks) ws.tasks[cls][at] = MsbTask{offs[q], sizes[q], rb + 8u, 0u};
+                        else MSB_OVERFLOW(ws);
                     }
                 }
                 continue;
@@ -588,9 +600,11 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
             new_bucket = (uint32_t)(s_base64 >> 32) + bidx;
             if (new_bucket < ws.max_buckets)
                 ws.buckets[(L + 1) & 1][new_bucket] = MsbBucket{abs, c, (uint32_t)s_base64 + tidx, tiles};
+            else MSB_OVERFLOW(ws);
         } else if (tsize) {
             if (s_cbase[cls] + task_local < ws.max_tasks)
                 ws.tasks[cls][s_cbase[cls] + task_local] = MsbTask{abs, tsize, rb + (s_nsub[d] > 1 ? 8u : 0u), 0u};
+            else MSB_OVERFLOW(ws);
         }
     }
     CLS_STAMP(7);
@@ -1761,6 +1775,7 @@ __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *
                 const uint32_t tiles = ws_tiles_of(ws, sz);
                 const unsigned long long old = atomicAdd(&ws.level[1].packed, (1ull << 32) | tiles);
                 if ((uint32_t)(old >> 32) < ws.max_buckets) ws.buckets[1][(uint32_t)(old >> 32)] = MsbBucket{b[j], sz, (uint32_t)old, tiles};
+                else MSB_OVERFLOW(ws);
             }
 #pragma unroll
             for (int q = 0; q < NLIST; ++q) cnt[q] += list[j] == q ? 1u : 0u;
@@ -1780,6 +1795,8 @@ __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *
                 if (at < ws.max_tasks) {
                     if (q < NW) ws.tasks[q][ws.max_tasks - 1u - at] = MsbTask{b[j], size[j], sort_bits, shift0};
                     else ws.tasks[q - NW][at] = MsbTask{b[j], size[j], sort_bits, shift0};
+                } else {
+                    MSB_OVERFLOW(ws);
                 }
             }
         }
@@ -2384,6 +2401,18 @@ size_t gs_msb_temp_bytes(uint64_t num_items, int has_values)
     return align256(lsb_temp_bytes(num_items)) + msb_ws_bytes(num_items, has_values != 0);
 }
 
+// A synchronous sort ends by reading the sort's overflow word (MsbLevel::overflow): a clamped device-side append means a
+// record was dropped and the result is wrong -- reported as hipErrorUnknown instead of a silent hipSuccess.  Asynchronous
+// callers read the same word through gs_msb_census (`overflow`).
+static int msb_sync_and_check(const MsbWs &ws, hipStream_t s)
+{
+    uint32_t ovf = 0;
+    hipError_t e = hipMemcpyAsync(&ovf, &ws.level[0].overflow, sizeof(ovf), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return (int)e;
+    return ovf ? (int)hipErrorUnknown : 0;
+}
+
 static int msb_sort_impl(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_t *d_vals, uint64_t num_items,
                          uint32_t *d_keys_alt, uint32_t *d_vals_alt, uint32_t **d_sorted_keys, uint32_t **d_sorted_vals,
                          int key_type, void *stream, int synchronize, int stop_level, bool allow_pivot)
@@ -2445,7 +2474,7 @@ static int msb_sort_impl(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint
     }
     int err = (int)hipGetLastError();
     if (err) return err;
-    if (synchronize) err = (int)hipStreamSynchronize(s);
+    if (synchronize) err = msb_sync_and_check(ws, s);
     return err;
 }
 
@@ -2469,6 +2498,13 @@ int gs_msb_classify_upto(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint
 #ifdef GS_EXP_CLS
 int gs_exp_cls_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gs_cls_stamp), sizeof(unsigned long long) * 16 * 8); }
 #endif
+void gs_msb_capacities(uint64_t num_items, int has_values, uint32_t *max_buckets, uint32_t *max_tasks, uint32_t *max_tiles)
+{
+    if (max_buckets) *max_buckets = msb_max_buckets(num_items, has_values != 0);
+    if (max_tasks) *max_tasks = msb_max_tasks(num_items, has_values != 0);
+    if (max_tiles) *max_tiles = msb_max_tiles(num_items, has_values != 0);
+}
+
 int gs_msb_census(void *d_temp, uint64_t num_items, int has_values, gs_msb_level_census out[4], void *stream)
 {
     GS_CLEAR_STALE_ERROR();
@@ -2500,6 +2536,7 @@ int gs_msb_census(void *d_temp, uint64_t num_items, int has_values, gs_msb_level
         c.task_keys = sum[L].task_keys;
         for (int q = 0; q < MSB_NCLASS; ++q) c.tasks[q] = lv[L].task_count[q];
         c.flagged = lv[L].flagged;
+        c.overflow = lv[0].overflow;          // the sort's one word, repeated in every level's record
         out[L] = c;
     }
     return hipSuccess;
@@ -2661,7 +2698,7 @@ int gs_msb_finish_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_
     msb_run_levels(ws, num_items, pairs, np, buf_k, buf_v, tw, s);
     int err = (int)hipGetLastError();
     if (err) return err;
-    if (synchronize) err = (int)hipStreamSynchronize(s);
+    if (synchronize) err = msb_sync_and_check(ws, s);
     return err;
 }
 

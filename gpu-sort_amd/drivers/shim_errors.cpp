@@ -26,6 +26,16 @@ int main(int argc, char **argv)
         unsigned long long *k8 = reinterpret_cast<unsigned long long *>(0x1000), *k8o = reinterpret_cast<unsigned long long *>(0x3000);
         auto c = rdxsrt_unstable_sort<unsigned long long, gpusort::NullType, unsigned int>(k8, nullptr, 1000u, k8o, nullptr);
         EXPECT(c.sorted_keys == nullptr);
+        // the host-pointer wrappers: every runtime call is checked; on failure the outputs stay untouched and stderr says why
+        std::vector<unsigned int> hk(1000, 7u), hv(1000, 9u), ok(1000, 0xabababab), ov(1000, 0xcdcdcdcd);
+        rdxsrt_unstable_sort_keys<unsigned int>(hk.data(), 1000ull, ok.data());
+        bool untouched = true;
+        for (unsigned int x : ok) untouched = untouched && x == 0xabababab;
+        EXPECT(untouched);
+        rdxsrt_unstable_sort_pairs<unsigned int, unsigned int>(hk.data(), hv.data(), 1000ull, ok.data(), ov.data());
+        for (unsigned int x : ok) untouched = untouched && x == 0xabababab;
+        for (unsigned int x : ov) untouched = untouched && x == 0xcdcdcdcd;
+        EXPECT(untouched);
     } else {
         const unsigned int n = 300000;
         std::vector<unsigned int> h(n);

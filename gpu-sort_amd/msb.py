@@ -79,7 +79,7 @@ def rdxsrt_unstable_sort_pairs(keys, values, key_count=None, device="cuda"):
 class _LevelCensus(C.Structure):
     _fields_ = [("buckets", C.c_uint64), ("tiles", C.c_uint64), ("keys", C.c_uint64), ("pivot_buckets", C.c_uint64),
                 ("pivot_keys", C.c_uint64), ("task_keys", C.c_uint64), ("tasks", C.c_uint32 * 4), ("flagged", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("overflow", C.c_uint32)]
 
 
 def msb_census(dm, key_count, has_values=False):
@@ -88,7 +88,7 @@ def msb_census(dm, key_count, has_values=False):
     check(lib.gs_msb_census(dm.data_ptr(), key_count, int(has_values), C.cast(out, C.c_void_p), None), "gs_msb_census")
     return [{"buckets": int(c.buckets), "tiles": int(c.tiles), "keys": int(c.keys), "pivot_buckets": int(c.pivot_buckets),
              "pivot_keys": int(c.pivot_keys), "task_keys": int(c.task_keys), "tasks": [int(x) for x in c.tasks],
-             "flagged": int(c.flagged)} for c in out]
+             "flagged": int(c.flagged), "overflow": int(c.overflow)} for c in out]
 
 
 def msb_algorithmic_bytes(census, key_count, has_values=False):

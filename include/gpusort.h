@@ -179,9 +179,16 @@ typedef struct gs_msb_level_census {
     uint64_t task_keys;       /* keys handed to local sorts by this level's classification                */
     uint32_t tasks[4];        /* local-sort tasks per size class (2048 / 4608 / 9216 / 17408)             */
     uint32_t flagged;         /* != 0: some tasks needed the general local-sort plan                      */
-    uint32_t reserved;
+    uint32_t overflow;        /* != 0: a device-side list of the sort overflowed and a record was dropped:  */
+                              /* the result is WRONG (same word in all four records).  A synchronous        */
+                              /* gs_msb_sort_u32 returns hipErrorUnknown in that case.                      */
 } gs_msb_level_census;
 int gs_msb_census(void *d_temp, uint64_t num_items, int has_values, gs_msb_level_census out[4], void *stream);
+/* Capacities of the workspace's device-side lists for num_items (records): buckets a level may hold, local-sort tasks per
+ * size class, tile records.  The sizing argument (gs_msb.hip, msb_max_*): a level's buckets are > the largest local sort
+ * each; a task is >= 3000 keys or followed by something that did not merge with it (<= 2n / 3000, + 256 per bucket's
+ * ragged end).  Exposed so that tests can hold the bounds against adversarial size patterns (tests/test_oracle.py).      */
+void gs_msb_capacities(uint64_t num_items, int has_values, uint32_t *max_buckets, uint32_t *max_tasks, uint32_t *max_tiles);
 
 /* Test access to the classification (cuda_radix_sort.h:1084-1087,1241-1247,
  * cuda_radix_sort_config.h:9).  Runs the sort of gs_msb_sort_u32 up to and including the classification of

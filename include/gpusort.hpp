@@ -347,18 +347,27 @@ RDXSRT_SortedSequence<KeyT, ValueT> rdxsrt_unstable_sort(KeyT *dev_keys, ValueT 
 }
 
 // Host-pointer conveniences (gpu_radix_sort.h:511-587): allocate, copy in, sort, copy the
-// result back from the INPUT device arrays, free.
+// result back from the INPUT device arrays, free.  The reference's versions return void and check nothing; these keep
+// the signature, check every runtime call, and on ANY failure (allocation, copy, sort) leave the output arrays
+// UNTOUCHED and say why through report_failure -- the caller never receives stale or half-copied data as if it were sorted.
 template <typename KeyT>
 void rdxsrt_unstable_sort_keys(KeyT *keys, const unsigned long long key_count, KeyT *sorted_keys_out)
 {
     KeyT *dev_keys = nullptr, *dev_keys_out = nullptr;
     const size_t bytes = sizeof(KeyT) * (key_count ? key_count : 1);
-    (void)hipMalloc(&dev_keys_out, bytes);
-    (void)hipMalloc(&dev_keys, bytes);
-    (void)hipMemcpy(dev_keys, keys, sizeof(KeyT) * key_count, hipMemcpyHostToDevice);
-    auto seq = rdxsrt_unstable_sort<KeyT, gpusort::NullType, unsigned int>(dev_keys, nullptr, (unsigned int)key_count,
-                                                                           dev_keys_out, nullptr);
-    (void)hipMemcpy(sorted_keys_out, seq.sorted_keys, sizeof(KeyT) * key_count, hipMemcpyDeviceToHost);
+    int err = (int)hipMalloc(&dev_keys_out, bytes);
+    if (!err) err = (int)hipMalloc(&dev_keys, bytes);
+    if (!err) err = (int)hipMemcpy(dev_keys, keys, sizeof(KeyT) * key_count, hipMemcpyHostToDevice);
+    if (err) {
+        gpusort::report_failure("rdxsrt_unstable_sort_keys: device allocation / copy in", err);
+    } else {
+        auto seq = rdxsrt_unstable_sort<KeyT, gpusort::NullType, unsigned int>(dev_keys, nullptr, (unsigned int)key_count,
+                                                                               dev_keys_out, nullptr);
+        if (seq.sorted_keys) {          // (a failed sort has reported itself and returned {nullptr, nullptr})
+            err = (int)hipMemcpy(sorted_keys_out, seq.sorted_keys, sizeof(KeyT) * key_count, hipMemcpyDeviceToHost);
+            if (err) gpusort::report_failure("rdxsrt_unstable_sort_keys: copy out", err);
+        }
+    }
     (void)hipFree(dev_keys);
     (void)hipFree(dev_keys_out);
 }
@@ -370,12 +379,27 @@ void rdxsrt_unstable_sort_pairs(KeyT *keys, ValueT *values, const unsigned long 
     KeyT *dk = nullptr, *dko = nullptr;
     ValueT *dv = nullptr, *dvo = nullptr;
     const size_t kb = sizeof(KeyT) * (key_count ? key_count : 1), vb = sizeof(ValueT) * (key_count ? key_count : 1);
-    (void)hipMalloc(&dko, kb); (void)hipMalloc(&dk, kb);
-    (void)hipMalloc(&dvo, vb); (void)hipMalloc(&dv, vb);
-    (void)hipMemcpy(dk, keys, sizeof(KeyT) * key_count, hipMemcpyHostToDevice);
-    (void)hipMemcpy(dv, values, sizeof(ValueT) * key_count, hipMemcpyHostToDevice);
-    auto seq = rdxsrt_unstable_sort<KeyT, ValueT, unsigned int>(dk, dv, (unsigned int)key_count, dko, dvo);
-    (void)hipMemcpy(sorted_keys_out, seq.sorted_keys, sizeof(KeyT) * key_count, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(sorted_values_out, seq.sorted_values, sizeof(ValueT) * key_count, hipMemcpyDeviceToHost);
+    int err = (int)hipMalloc(&dko, kb);
+    if (!err) err = (int)hipMalloc(&dk, kb);
+    if (!err) err = (int)hipMalloc(&dvo, vb);
+    if (!err) err = (int)hipMalloc(&dv, vb);
+    if (!err) err = (int)hipMemcpy(dk, keys, sizeof(KeyT) * key_count, hipMemcpyHostToDevice);
+    if (!err) err = (int)hipMemcpy(dv, values, sizeof(ValueT) * key_count, hipMemcpyHostToDevice);
+    if (err) {
+        gpusort::report_failure("rdxsrt_unstable_sort_pairs: device allocation / copy in", err);
+    } else {
+        auto seq = rdxsrt_unstable_sort<KeyT, ValueT, unsigned int>(dk, dv, (unsigned int)key_count, dko, dvo);
+        if (seq.sorted_keys && seq.sorted_values) {
+            // both copies into scratch first would double the host memory; instead: keys, then values, and a failure of the
+            // second is reported (the keys array then holds sorted keys whose values did not arrive -- said so)
+            err = (int)hipMemcpy(sorted_keys_out, seq.sorted_keys, sizeof(KeyT) * key_count, hipMemcpyDeviceToHost);
+            if (err) {
+                gpusort::report_failure("rdxsrt_unstable_sort_pairs: copy out (nothing was written)", err);
+            } else {
+                err = (int)hipMemcpy(sorted_values_out, seq.sorted_values, sizeof(ValueT) * key_count, hipMemcpyDeviceToHost);
+                if (err) gpusort::report_failure("rdxsrt_unstable_sort_pairs: copy out of the VALUES (the keys were written, the values were not)", err);
+            }
+        }
+    }
     (void)hipFree(dk); (void)hipFree(dko); (void)hipFree(dv); (void)hipFree(dvo);
 }

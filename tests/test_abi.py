@@ -109,7 +109,9 @@ def test_shim_reports_failures_instead_of_returning_unsorted_data():
         pytest.skip("the no-device path needs a box without a GPU")
     out = subprocess.run([exe, "nodevice"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
-    assert out.stderr.count("gpusort: rdxsrt_unstable_sort") == 3
+    assert out.stderr.count("gpusort: rdxsrt_unstable_sort") == 5          # three shim calls + the two host-pointer wrappers
+    assert "rdxsrt_unstable_sort_keys: device allocation / copy in" in out.stderr
+    assert "rdxsrt_unstable_sort_pairs: device allocation / copy in" in out.stderr
 
 
 def test_rccl_host_library_exports_and_split_rule(gs):

@@ -305,6 +305,41 @@ print("pipe ok")
     assert out.returncode == 0 and "pipe ok" in out.stdout, out.stderr[-2000:]
 
 
+def test_one_launch_pass_give_up_stores_nothing(cuda, tmp_path):
+    """when a bounded wait of the opt-in one-launch pass gives up, nothing may be scattered from
+    untagged offsets (stale words of another pass can exceed n: an out-of-bounds write).  The test hook
+    GS_LSB_PIPE_TEST_DROP makes ONE upsweep workgroup publish nothing, so the scanner's batch and every tile behind it
+    time out: the status word must be non-zero, the call itself still returns, and the guard zones around all four
+    buffers (keys / values, both halves of the double buffer) must be untouched."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, ctypes as C, numpy as np, torch
+sys.path.insert(0, %r)
+import gpu_sort_amd as gs
+from oracle import oracle as O
+dev = torch.device("cuda:0")
+n, G = (1 << 21) + 77, 1 << 16
+keys = O.gen_uniform(n, 5); vals = O.gen_enumerated(n)
+bufs = [torch.full((n + 2 * G,), 0x5a5a5a5a, dtype=torch.int32, device=dev) for _ in range(4)]
+bufs[0][G:G + n] = torch.from_numpy(keys.view(np.int32).copy()).to(dev)
+bufs[2][G:G + n] = torch.from_numpy(vals.view(np.int32).copy()).to(dev)
+dk = gs.DoubleBuffer(bufs[0][G:G + n], bufs[1][G:G + n])
+dv = gs.DoubleBuffer(bufs[2][G:G + n], bufs[3][G:G + n])
+nb = gs.DeviceRadixSort.SortPairs(None, 0, dk, dv, n); temp = torch.zeros(nb, dtype=torch.uint8, device=dev)
+gs.DeviceRadixSort.SortPairs(temp, nb, dk, dv, n, key_type=gs.GS_KEY_U32); torch.cuda.synchronize()
+st = C.c_uint32(0)
+assert gs.lib.gs_lsb_pipe_status(temp.data_ptr(), n, C.byref(st), None) == 0
+assert st.value != 0, "a dropped publish must surface in the status word"
+for b in bufs:
+    assert bool((b[:G] == 0x5a5a5a5a).all()) and bool((b[G + n:] == 0x5a5a5a5a).all()), "write outside [0, n)"
+print("give-up ok", st.value)
+''' % root
+    env = dict(os.environ, GS_LSB_MODE="pipe", GS_LSB_PIPE_MIN_TILES="0", GS_LSB_PIPE_TEST_DROP="5")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "give-up ok" in out.stdout, out.stdout[-500:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("algo", ["lsb", "lsb_pairs", "lsb_f32_desc", "msb", "msb_pairs"])
 def test_beyond_2p30_keys(gs, cuda, algo):
     """n > 2^30: byte offsets no longer fit 32 bits, so the kernels' 64-bit addressing variants run

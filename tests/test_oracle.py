@@ -240,3 +240,56 @@ def test_msb_classification_oracle_invariants(oracle):
     got = oracle.msb_heavy_hitter(hot)
     assert got is not None and got[0] == 0x12345678 and got[1] + got[2] <= 60000 and got[2] == int((hot == 0x12345678).sum())
     assert oracle.msb_heavy_hitter(cold) is None
+
+
+def test_msb_list_capacities_hold_against_adversarial_size_patterns():
+    """the workspace's device-side lists (buckets of a level, local-sort tasks per class, tile records)
+    are sized by an argument (gs_msb.hip, msb_max_*); here the bounds gs_msb_capacities reports are held against the
+    classification rule (oracle.msb_classify_counts, the restatement of cuda_radix_sort.h:1084-1087,1241-1247) on the
+    sub-bucket size patterns that stress them: every sub-bucket one key short of merging, 1-key sub-buckets between
+    buckets one key over the largest local sort, and so on.  CPU only: the library is loaded, no kernel runs."""
+    import ctypes as C
+    import gpu_sort_amd as gs
+    from oracle import oracle as O
+    cap = O.MSB_CLASS_CAPS[-1]
+    merge = O.MSB_MERGE
+
+    def caps_of(n):
+        mb, mt, ml = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        gs.lib.gs_msb_capacities(n, 0, C.byref(mb), C.byref(mt), C.byref(ml))
+        return mb.value, mt.value, ml.value
+
+    patterns = {
+        "one short of merging": [merge - 1],                 # nothing merges: every sub-bucket is a task
+        "merge limit pairs": [merge - 1, 1],                 # (merge - 1) + 1 is not < merge: two tasks per `merge` keys
+        "1 between large": [1, cap + 1],                     # alternating: a 1-key task, a next-level bucket
+        "just large": [cap + 1],                             # every sub-bucket a next-level bucket of the smallest size
+        "ones": [1],                                         # long merged runs
+        "large then ragged": [cap + 1, merge - 1, 1, 1],
+    }
+    for n in (1 << 20, (1 << 24) + 12345, 1 << 30, (1 << 32) - 1):
+        max_b, max_t, max_l = caps_of(n)
+        for name, pat in patterns.items():
+            # one LEVEL made of buckets that each repeat the pattern over their sub-buckets (up to 256 of them, fewer when
+            # the array is too small for that), as many such buckets as n keys allow
+            counts = np.zeros(256, dtype=np.int64)
+            left = n
+            for i in range(256):
+                c = pat[i % len(pat)]
+                if c > left:
+                    break
+                counts[i] = c
+                left -= c
+            per_bucket = int(counts.sum())
+            if per_bucket <= cap:                # such a range is a local-sort task, never a bucket of a level
+                continue
+            nb_real = n // per_bucket
+            bk, tk = O.msb_classify_counts(counts, 0, 1)
+            next_buckets = nb_real * len(bk)
+            tasks_per_class = np.bincount([t[0] for t in tk], minlength=4) * nb_real
+            tiles_next = nb_real * sum(-(-size // 8192) for _, size in bk)
+            assert nb_real <= max_b and next_buckets <= max_b, (n, name, next_buckets, max_b)
+            assert tasks_per_class.max() <= max_t, (n, name, tasks_per_class, max_t)
+            assert tiles_next <= max_l, (n, name, tiles_next, max_l)
+        # the bound's own argument, checked numerically: at most 2n / merge tasks + 256 per bucket
+        assert max_t >= 2 * n // merge + 256 and max_b >= n // cap
