@@ -1560,19 +1560,31 @@ static bool msb_peek_enabled()
     static const bool on = [] { const char *e = getenv("GS_MSB_PEEK"); return !(e && e[0] == '0'); }();
     return on;
 }
+// The calling thread's mailboxes, one per device it has sorted on (a host thread that drives several GPUs keeps them all:
+// re-creating the pinned word on every switch would hipHostFree -- a device synchronisation -- inside every sort), released
+// when the thread ends.
+constexpr int MSB_PEEK_DEVICES = 16;
+struct MsbPeekTable {
+    MsbPeek slot[MSB_PEEK_DEVICES];
+    ~MsbPeekTable()
+    {
+        for (MsbPeek &pk : slot) {
+            if (pk.ev) (void)hipEventDestroy(pk.ev);
+            if (pk.host) (void)hipHostFree(pk.host);
+        }
+    }
+};
 // the calling thread's mailbox for the current device, or nullptr (then the caller keeps the worst-case grids)
 static MsbPeek *msb_peek_get(hipStream_t s)
 {
     if (!msb_peek_enabled()) return nullptr;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
-    thread_local MsbPeek pk;
+    thread_local MsbPeekTable table;
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MSB_PEEK_DEVICES) { (void)hipGetLastError(); return nullptr; }
+    MsbPeek &pk = table.slot[dev];
     if (pk.device != dev) {
-        if (pk.ev) { (void)hipEventDestroy(pk.ev); pk.ev = nullptr; }
-        if (pk.host) { (void)hipHostFree(pk.host); pk.host = nullptr; }
-        pk.device = -1;
         void *h = nullptr, *d = nullptr;
         if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess ||
             hipHostGetDevicePointer(&d, h, 0) != hipSuccess ||
@@ -1584,6 +1596,9 @@ static MsbPeek *msb_peek_get(hipStream_t s)
         }
         pk.host = (unsigned long long *)h; pk.dev = (unsigned long long *)d; pk.device = dev;
     }
+    // a look armed by an earlier call that returned early (an error between arm and wait): its kernel may still be about
+    // to write the mailbox -- wait it out before the word is reused
+    if (pk.armed) { (void)hipEventSynchronize(pk.ev); (void)hipGetLastError(); }
     pk.armed = false;
     return &pk;
 }
@@ -1623,7 +1638,7 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
     const uint32_t max_tasks_lvl = ws.max_tasks;
     uint32_t *d_keys = buf_k[0], *d_vals = buf_v[0];
     // (not in the multi-GPU finish, npieces != 0: that path stays free of host waits between its collectives)
-    MsbPeek *peek = (stop_level == 99 && npieces == 0) ? msb_peek_get(s) : nullptr;
+    MsbPeek *peek = (stop_level == 99 && (npieces == 0 || getenv("GS_MSB_PEEK_FINISH"))) ? msb_peek_get(s) : nullptr;   // env: diagnosis only
     uint32_t known_b = 0, known_tiles = 0;     // level L's exact bucket / tile counts when the look succeeded
     bool known = false;
     for (int L = 1; L <= 3; ++L) {

@@ -10,8 +10,11 @@
  * Conventions
  *   - every pointer named d_* is a DEVICE pointer owned by the caller;
  *   - return value: 0 (= hipSuccess) or a hipError_t value; nothing throws;
- *   - no global mutable state; entry points are re-entrant given distinct
- *     streams and workspaces; `stream` is a hipStream_t passed as void*;
+ *   - entry points are re-entrant given distinct streams and workspaces (tests/test_concurrency_gpu.py); `stream`
+ *     is a hipStream_t passed as void*.  State outside the caller's buffers: a few switches read from the
+ *     environment (most once per process; INTEGRATION.md lists them), and per host thread one pinned 64-byte
+ *     mailbox + event per device the thread has run an MSB sort on (the "look" of DESIGN.md section 1), released
+ *     when the thread ends; nothing else persists between calls;
  *   - LSB entry points only enqueue work on `stream` and return (like
  *     cub::DeviceRadixSort, dispatch_radix_sort.cuh:899-979);
  *   - counts are 64-bit in the signature; the current kernels index with
