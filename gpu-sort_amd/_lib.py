@@ -19,6 +19,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 GS_KEY_U32, GS_KEY_I32, GS_KEY_F32, GS_KEY_U64, GS_KEY_I64, GS_KEY_F64 = 0, 1, 2, 3, 4, 5
+GS_KEY_U8, GS_KEY_I8, GS_KEY_U16, GS_KEY_I16 = 6, 7, 8, 9
 GS_GEN_UNIFORM, GS_GEN_ZIPF, GS_GEN_ENTROPY_AND, GS_GEN_ENUMERATED = 0, 1, 2, 3
 
 u64, i32, vp, sz = C.c_uint64, C.c_int, C.c_void_p, C.c_size_t
@@ -34,6 +35,8 @@ SIGNATURES = {
     "gs_lsb_sort_copy_u32": (i32, [vp, sz, vp, vp, vp, vp, u64, i32, i32, i32, i32, vp]),
     "gs_lsb_wide_temp_bytes": (sz, [u64, i32, i32]),
     "gs_lsb_sort_wide": (i32, [vp, sz, pp, pp, C.POINTER(i32), u64, i32, i32, i32, i32, i32, i32, vp]),
+    "gs_lsb_any_temp_bytes": (sz, [u64, i32, i32]),
+    "gs_lsb_sort_any": (i32, [vp, sz, vp, vp, vp, vp, u64, i32, i32, i32, i32, i32, vp]),
     "gs_lsb_geometry": (None, [u64, i32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gs_lsb_workspace_layout": (i32, [vp, u64, pp, pp, pp]),
     "gs_lsb_pipe_status": (i32, [vp, u64, C.POINTER(C.c_uint32), vp]),

@@ -23,12 +23,31 @@ template <> const char *name_of<unsigned long long>() { return "u64"; }
 template <> const char *name_of<long long>() { return "i64"; }
 template <> const char *name_of<double>() { return "f64"; }
 template <> const char *name_of<gpusort::NullType>() { return "-"; }
+template <> const char *name_of<bool>() { return "bool"; }
+template <> const char *name_of<char>() { return "char"; }
+template <> const char *name_of<signed char>() { return "i8"; }
+template <> const char *name_of<unsigned char>() { return "u8"; }
+template <> const char *name_of<short>() { return "i16"; }
+template <> const char *name_of<unsigned short>() { return "u16"; }
+// the reference's 16-byte value type (lsb/cub/test/test_util.h:1004-1010), restated: assignable from an int, comparable
+struct TestFoo {
+    long long x; int y; short z; char w;
+    TestFoo() : x(0), y(0), z(0), w(0) {}
+    explicit TestFoo(int b) : x(b), y(b), z((short)b), w((char)b) {}
+    bool operator!=(const TestFoo &o) const { return x != o.x || y != o.y || z != o.z || w != o.w; }
+};
+static_assert(sizeof(TestFoo) == 16, "TestFoo is a 16-byte value");
+template <> const char *name_of<TestFoo>() { return "TestFoo"; }
 
-template <typename KeyT> static void fill_keys(std::vector<KeyT> &k, std::mt19937_64 &rng)
+// host copies of bool keys live in unsigned chars (std::vector<bool> is a bit set)
+template <typename T> using HostT = typename std::conditional<std::is_same<T, bool>::value, unsigned char, T>::type;
+
+template <typename KeyT> static void fill_keys(std::vector<HostT<KeyT>> &k, std::mt19937_64 &rng)
 {
     for (auto &x : k) {
         do {                                              // test_util.h RandomBits: no NaNs
             unsigned long long bits = rng() & rng();      // a little entropy reduction -> duplicates
+            if (std::is_same<KeyT, bool>::value) bits &= 1ull;    // a bool holds 0 or 1
             memcpy(&x, &bits, sizeof(KeyT));
         } while (x != x);
     }
@@ -40,8 +59,8 @@ static int test_case(int n, bool descending)
     constexpr bool PAIRS = !std::is_same<ValueT, gpusort::NullType>::value;
     using StoreV = typename std::conditional<PAIRS, ValueT, unsigned int>::type;
     std::mt19937_64 rng(1234 + n);
-    std::vector<KeyT> h_keys(n);
-    fill_keys(h_keys, rng);
+    std::vector<HostT<KeyT>> h_keys(n);
+    fill_keys<KeyT>(h_keys, rng);
     std::vector<StoreV> h_vals(n);
     for (int i = 0; i < n; ++i) h_vals[i] = (StoreV)i;
 
@@ -87,7 +106,7 @@ static int test_case(int n, bool descending)
     HIP_OK(hipMalloc(&d_temp, temp_bytes ? temp_bytes : 1));
     HIP_OK(run());
     HIP_OK(hipDeviceSynchronize());
-    std::vector<KeyT> out_k(n);
+    std::vector<HostT<KeyT>> out_k(n);
     std::vector<StoreV> out_v(n);
     HIP_OK(hipMemcpy(out_k.data(), keys.Current(), (size_t)n * sizeof(KeyT), hipMemcpyDeviceToHost));
     if (PAIRS) HIP_OK(hipMemcpy(out_v.data(), vals.Current(), (size_t)n * sizeof(StoreV), hipMemcpyDeviceToHost));
@@ -167,6 +186,18 @@ int main(int argc, char **argv)
     bad += test_type<unsigned long long, gpusort::NullType>(n);
     bad += test_type<long long, unsigned int>(n);
     bad += test_type<double, unsigned long long>(n);
+    // 8- and 16-bit keys, 1- / 2- / 16-byte values (test_device_radix_sort.cu:930-945,1244-1250)
+    const int ns = n < 300007 ? n : 300007;
+    bad += test_type<bool, gpusort::NullType>(ns);
+    bad += test_type<char, char>(ns);
+    bad += test_type<signed char, unsigned int>(ns);
+    bad += test_type<unsigned char, unsigned long long>(ns);
+    bad += test_type<short, short>(ns);
+    bad += test_type<unsigned short, TestFoo>(ns);
+    bad += test_type<unsigned short, gpusort::NullType>(ns);
+    bad += test_type<unsigned int, TestFoo>(ns);
+    bad += test_type<long long, TestFoo>(ns);
+    bad += test_type<double, unsigned short>(ns);
     bad += test_segmented<unsigned int>(n, 1, false, "u32");
     bad += test_segmented<unsigned int>(n, 37, true, "u32");
     bad += test_segmented<unsigned int>(n, 5000, false, "u32");

@@ -14,6 +14,9 @@ from ._lib import lib, check
 
 _KEY_TYPES = {torch.int32: _lib.GS_KEY_I32, torch.float32: _lib.GS_KEY_F32,
               torch.int64: _lib.GS_KEY_I64, torch.float64: _lib.GS_KEY_F64}
+_KEY_TYPES.update({torch.uint8: _lib.GS_KEY_U8, torch.bool: _lib.GS_KEY_U8, torch.int8: _lib.GS_KEY_I8, torch.int16: _lib.GS_KEY_I16})
+if hasattr(torch, "uint16"):
+    _KEY_TYPES[torch.uint16] = _lib.GS_KEY_U16
 if hasattr(torch, "uint32"):
     _KEY_TYPES[torch.uint32] = _lib.GS_KEY_U32
 if hasattr(torch, "uint64"):
@@ -55,7 +58,16 @@ class DeviceRadixSort:
               stream, key_type):
         has_values = d_values is not None
         kb = d_keys.d_buffers[0].element_size()
-        vb = d_values.d_buffers[0].element_size() if has_values else 0
+        vb = 0
+        if has_values:      # a value is one element of a 1-D tensor or one row of a 2-D one (records: 16-byte rows ...)
+            v0 = d_values.d_buffers[0]
+            row = 1
+            for d in v0.shape[1:]:
+                row *= d
+            vb = v0.element_size() * row
+        if kb < 4 or vb not in (0, 4, 8):
+            return DeviceRadixSort._sort_any(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, begin_bit,
+                                             end_bit, descending, stream, key_type, kb, vb)
         if kb == 8 or vb == 8:
             return DeviceRadixSort._sort_wide(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, begin_bit,
                                               end_bit, descending, stream, key_type, kb, vb)
@@ -84,6 +96,42 @@ class DeviceRadixSort:
         d_keys.selector = sel.value
         if has_values:
             d_values.selector = sel.value
+        return need
+
+    @staticmethod
+    def _sort_any(d_temp_storage, temp_storage_bytes, d_keys, d_values, num_items, begin_bit, end_bit, descending,
+                  stream, key_type, kb, vb):
+        """8- and 16-bit keys (torch.bool / uint8 / int8 / int16 [/ uint16]) and values of any size (1- and 2-byte
+        elements, or rows of a 2-D tensor: 16-byte records like the reference's TestFoo): gs_lsb_sort_any.  It is the
+        plain-pointer form underneath (input untouched, result in the other buffer), so the sorted data ALWAYS ends in
+        the alternate buffer and the selector flips once -- a DoubleBuffer contract as good as any other."""
+        if key_type is None:
+            key_type = _KEY_TYPES.get(d_keys.d_buffers[0].dtype)
+            if key_type is None:
+                raise TypeError(f"no key category for dtype {d_keys.d_buffers[0].dtype}: pass key_type")
+        need = lib.gs_lsb_any_temp_bytes(num_items, key_type, vb)
+        if d_temp_storage is None:
+            return need
+        if end_bit is None:
+            end_bit = 8 * kb
+        for b in d_keys.d_buffers:
+            _check_buf(b, num_items, "d_keys", kb)
+        if vb:
+            for b in d_values.d_buffers:
+                _check_buf(b, num_items * (vb // b.element_size()), "d_values", b.element_size())
+            if d_values.selector != d_keys.selector:
+                raise ValueError("d_keys and d_values selectors differ")
+        sel = d_keys.selector
+        err = lib.gs_lsb_sort_any(C.c_void_p(d_temp_storage.data_ptr()),
+                                  min(temp_storage_bytes, d_temp_storage.numel() * d_temp_storage.element_size()),
+                                  d_keys.d_buffers[sel].data_ptr(), d_keys.d_buffers[sel ^ 1].data_ptr(),
+                                  d_values.d_buffers[sel].data_ptr() if vb else None,
+                                  d_values.d_buffers[sel ^ 1].data_ptr() if vb else None, num_items, key_type, vb,
+                                  begin_bit, end_bit, int(descending), _stream_ptr(stream))
+        check(err, "gs_lsb_sort_any")
+        d_keys.selector = sel ^ 1
+        if vb:
+            d_values.selector = sel ^ 1
         return need
 
     @staticmethod

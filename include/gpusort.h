@@ -42,7 +42,11 @@ enum gs_key_type {
     GS_KEY_F32 = 2,   /* negative: flip all bits; else flip sign   */
     GS_KEY_U64 = 3,   /* 64-bit keys: gs_lsb_sort_wide only        */
     GS_KEY_I64 = 4,
-    GS_KEY_F64 = 5
+    GS_KEY_F64 = 5,
+    GS_KEY_U8 = 6,    /* 8- and 16-bit keys: gs_lsb_sort_any only   */
+    GS_KEY_I8 = 7,    /* (bool / unsigned char: U8; char / signed   */
+    GS_KEY_U16 = 8,   /*  char: I8; unsigned short / short)         */
+    GS_KEY_I16 = 9
 };
 
 int         gs_version(void);
@@ -127,6 +131,17 @@ int  gs_lsb_downsweep_u32(void *d_temp, size_t temp_bytes,
                           const uint32_t *d_vals_in, uint32_t *d_vals_out,
                           uint64_t num_items, int shift, int bits, int descending,
                           int key_type_in, int key_type_out, void *stream);
+
+/* The rest of DeviceRadixSort's type contract (lsb/cub/test/test_device_radix_sort.cu:930-945,1244-1265): keys of 8, 16, 32
+ * or 64 bits (key_type names width and category) with values of ANY size -- none (val_bytes 0), the 1- and 2-byte values of
+ * TestBackend<KeyT, KeyT>, the 16-byte TestFoo (test_util.h:1004-1010), ... -- stable, ascending or descending, on the bits
+ * [begin_bit, end_bit) of the key's own width.  Plain-pointer form: the input arrays are untouched, the result is written
+ * to the output arrays (which must not alias the inputs; 16-byte values must be 16-byte aligned).  Built on the library's
+ * stable sort of (order-preserving sort key, index) pairs and one gather (gs_any.hip); only enqueues work on `stream`.   */
+size_t gs_lsb_any_temp_bytes(uint64_t num_items, int key_type, int val_bytes);
+int gs_lsb_sort_any(void *d_temp, size_t temp_bytes, const void *d_keys_in, void *d_keys_out,
+                    const void *d_vals_in, void *d_vals_out, uint64_t num_items, int key_type, int val_bytes,
+                    int begin_bit, int end_bit, int descending, void *stream);
 
 /* ------------------------------------------------------------------ MSB --
  * Unstable most-significant-digit hybrid radix sort, ascending.

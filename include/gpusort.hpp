@@ -51,6 +51,13 @@ template <> struct KeyTraits<unsigned long> { static constexpr int type = sizeof
 template <> struct KeyTraits<long long> { static constexpr int type = GS_KEY_I64; };
 template <> struct KeyTraits<long> { static constexpr int type = sizeof(long) == 8 ? GS_KEY_I64 : GS_KEY_I32; };
 template <> struct KeyTraits<double> { static constexpr int type = GS_KEY_F64; };
+// 8- and 16-bit keys (test_device_radix_sort.cu:1244-1250): through gs_lsb_sort_any
+template <> struct KeyTraits<bool> { static constexpr int type = GS_KEY_U8; };
+template <> struct KeyTraits<unsigned char> { static constexpr int type = GS_KEY_U8; };
+template <> struct KeyTraits<signed char> { static constexpr int type = GS_KEY_I8; };
+template <> struct KeyTraits<char> { static constexpr int type = (char)-1 < 0 ? GS_KEY_I8 : GS_KEY_U8; };
+template <> struct KeyTraits<unsigned short> { static constexpr int type = GS_KEY_U16; };
+template <> struct KeyTraits<short> { static constexpr int type = GS_KEY_I16; };
 
 struct DeviceRadixSort {
     template <typename KeyT, typename ValueT>
@@ -59,8 +66,28 @@ struct DeviceRadixSort {
                                bool descending, hipStream_t stream)
     {
         constexpr int VB = std::is_same<ValueT, NullType>::value ? 0 : (int)sizeof(ValueT);
-        static_assert(sizeof(KeyT) == 4 || sizeof(KeyT) == 8, "32- or 64-bit keys");
-        static_assert(VB == 0 || VB == 4 || VB == 8, "32- or 64-bit values");
+        static_assert(sizeof(KeyT) == 1 || sizeof(KeyT) == 2 || sizeof(KeyT) == 4 || sizeof(KeyT) == 8, "8-, 16-, 32- or 64-bit keys");
+        if constexpr (sizeof(KeyT) < 4 || (VB != 0 && VB != 4 && VB != 8)) {
+            // 8- and 16-bit keys, values of any other size (1, 2, 16, ... bytes: TestBackend<KeyT, KeyT>, TestFoo): gs_lsb_sort_any.
+            // It is the plain-pointer form underneath, so the result always lands in the ALTERNATE buffer and the
+            // selector flips once.
+            const int vb = d_values ? VB : 0;
+            const size_t need_a = gs_lsb_any_temp_bytes((uint64_t)num_items, KeyTraits<KeyT>::type, vb);
+            if (d_temp_storage == nullptr) {
+                temp_storage_bytes = need_a;
+                return hipSuccess;
+            }
+            const int sel_a = d_keys.selector;
+            const int err_a = gs_lsb_sort_any(d_temp_storage, temp_storage_bytes, d_keys.d_buffers[sel_a], d_keys.d_buffers[sel_a ^ 1],
+                                              d_values ? (const void *)d_values->d_buffers[sel_a] : nullptr,
+                                              d_values ? (void *)d_values->d_buffers[sel_a ^ 1] : nullptr, (uint64_t)num_items,
+                                              KeyTraits<KeyT>::type, vb, begin_bit, end_bit, descending ? 1 : 0, stream);
+            if (err_a == 0 && num_items > 0) {
+                d_keys.selector = sel_a ^ 1;
+                if (d_values) d_values->selector = sel_a ^ 1;
+            }
+            return static_cast<hipError_t>(err_a);
+        } else
         if constexpr (sizeof(KeyT) == 8 || VB == 8) {      // general kernels (gs_lsb_sort_wide)
             const size_t need_w = gs_lsb_wide_temp_bytes((uint64_t)num_items, (int)sizeof(KeyT), d_values ? VB : 0);
             if (d_temp_storage == nullptr) {
