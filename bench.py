@@ -96,6 +96,16 @@ def load_pmc_traffic(pairs=False):
         return None
 
 
+def load_pmc_traffic_msb(dist):
+    """{kernel group: HBM bytes per sort} of the MSB path from the committed --pmc summary (profiles/pmc_traffic_msb.json), or {}."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_msb.json")) as f:
+            d = json.load(f)
+        return d.get(dist, {}).get("hbm_bytes_per_sort", {}) if d.get("log2n") == 30 else {}
+    except Exception:
+        return {}
+
+
 def cpu_baseline(n_log2, pairs):
     from oracle import oracle as O
     n = 1 << n_log2
@@ -228,7 +238,7 @@ def also_configs(gs, torch, dev, n, steps, log2n):
             "ms_device_median": round(med, 4), "ms_device_min": round(mn, 4), "rate": round(n / med / 1e6, 3), "unit": "Gkeys/s",
             "algorithmic_bytes_per_key": round(tot / n, 2), "whole_sort_frac_of_peak": round(tot / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {"kernel": dom, "algorithmic_bytes": by[dom], "ms_per_sort": round(per_sort[dom], 4), "achieved": round(gbs, 1),
-                         "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": (load_pmc_traffic_msb(dist_name).get(dom) if log2n == 30 else None),
                          "all_kernel_groups": {g: {"algorithmic_bytes": by[g], "ms_per_sort": round(per_sort[g], 4),
                                                    "frac": round(by[g] / (per_sort[g] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for g in per_sort}},
             "verified": bool(invs == 0 and (sm, xr) == pre), "check": "sorted on the device + multiset checksum of the input"}
@@ -486,8 +496,9 @@ def main():
             per_sort = {k: kernels[k][0] / steps for k in by if k in kernels}
             dom = max(per_sort, key=per_sort.get)
             achieved = by[dom] / (per_sort[dom] * 1e-3) / 1e9
+            msb_traffic = load_pmc_traffic_msb(args.dist) if (args.log2n == 30 and not args.pairs) else {}
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": msb_traffic.get(dom),
                         "algorithmic_bytes_per_sort": by[dom], "ms_per_sort": round(per_sort[dom], 4),
                         "launches_per_sort": kernels[dom][1] // steps,
                         "all_kernel_groups": {k: {"algorithmic_bytes": by[k], "ms_per_sort": round(per_sort[k], 4),

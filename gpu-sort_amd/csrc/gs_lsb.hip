@@ -129,7 +129,10 @@ __device__ __forceinline__ void upsweep_chunk(UpsweepSmem<NEXT, PIPE> &sm, const
         }
     }
     __syncthreads();
-#if defined(GS_EXP_UPS) && GS_EXP_UPS >= 1
+#if defined(GS_EXP_UPS) && GS_EXP_UPS == 4
+    if (!PIPE && !NEXT && (chunk & 7u) != 0u) return;     // timing experiment: only one workgroup in eight writes its results
+#endif
+#if defined(GS_EXP_UPS) && GS_EXP_UPS >= 1 && GS_EXP_UPS <= 3
     // timing experiments only (results land in the wrong layout): 1 = the chunk's prefix16 rows as ONE 16-byte store per
     // digit thread (4 KiB per workgroup in four wave instructions instead of 32), 2 = also the spine as one 1 KiB row per
     // chunk, 3 = no result stores at all

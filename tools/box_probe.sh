@@ -11,6 +11,9 @@ timeout -k 10 150 rocprofv3 --pmc TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANS
     --output-format csv -d $R/gpurun_out/pmc_probe -- python3 $R/tools/one_sort.py 30 pairs 1 > /dev/null 2>&1
 ( cd $R && python3 tools/pmc_summary.py gpurun_out/pmc_probe | grep downsweep ) > $R/gpurun_out/box_probe_$T.pmc.txt 2>&1
 rm -rf $R/gpurun_out/pmc_probe
+( timeout -k 10 120 $R/tools/micro/lsb_floor 30 8 probe 2>&1 | grep -E "pattern|real" ) > $R/gpurun_out/box_probe_$T.patterns.txt
+( timeout -k 10 60 $R/tools/micro/stream 2>&1 | tail -12 ) > $R/gpurun_out/box_probe_$T.stream.txt
+cat $R/gpurun_out/box_probe_$T.patterns.txt | cut -c1-150
 cat $R/gpurun_out/box_probe_$T.pmc.txt
 python3 - <<PY
 import json

@@ -486,6 +486,15 @@ int main(int argc, char **argv)
         run_pattern<13, false, 0>(raw, out, n, 2);
         return 0;
     }
+    if (argc > 3 && !strcmp(argv[3], "probe")) {   // a few patterns for tools/box_probe.sh: what differs between boxes
+        run_pattern<13, false, 0>(raw, out, n, 3);
+        run_pattern<5, false, 0>(raw, out, n, 3);
+        run_pattern<5, true, 0>(raw, out, n, 3);
+        run_pattern<4, false, 0>(raw, out, n, 3);
+        run_pattern<4, true, 0>(raw, out, n, 3);
+        run_pattern<5, true, 0, true>(raw, out, n, 3);
+        return 0;
+    }
     run_patterns(raw, out, n, reps);
     run_geometry<8, 16, 6>(raw, sorted_tiles, permuted, out, expect, temp, temp_bytes, n, shift, reps);     // the real kernel's shape
     run_geometry<16, 16, 8>(raw, sorted_tiles, permuted, out, expect, temp, temp_bytes, n, shift, reps);    // 16384 keys, 64 VGPRs, 2 per CU
