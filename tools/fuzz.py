@@ -179,6 +179,61 @@ def wide_case(it):
             fail("wide MSB values", **case)
 
 
+def any_case(it):
+    """gs_lsb_sort_any: 8- / 16-bit keys (and 32-bit keys with odd value sizes) with values of 0 / 1 / 2 / 4 / 8 / 16 bytes, against
+    torch's stable sort of the keys' order-preserving images"""
+    n = min(max(0, pick_n()), 2_000_000)
+    kt = str(rng.choice(["u8", "i8", "i16", "u16", "bool", "u32", "i32"]))
+    bits = {"u8": 8, "i8": 8, "bool": 8, "i16": 16, "u16": 16, "u32": 32, "i32": 32}[kt]
+    gtype = {"u8": gs.GS_KEY_U8, "bool": gs.GS_KEY_U8, "i8": gs.GS_KEY_I8, "i16": gs.GS_KEY_I16, "u16": gs.GS_KEY_U16,
+             "u32": gs.GS_KEY_U32, "i32": gs.GS_KEY_I32}[kt]
+    vb = int(rng.choice([0, 1, 2, 4, 8, 16])) if bits < 32 else int(rng.choice([1, 2, 16]))
+    g = torch.Generator(device=dev); g.manual_seed(int(rng.integers(0, 2**31)))
+    raw = torch.randint(0, 1 << 31, (max(n, 1),), device=dev, generator=g, dtype=torch.int64)[:n]
+    if rng.random() < 0.4:
+        raw = raw & torch.randint(0, 1 << 31, (max(n, 1),), device=dev, generator=g, dtype=torch.int64)[:n]
+    img = raw & ((1 << bits) - 1)                       # unsigned bit pattern of the key
+    if kt == "bool":
+        img = img & 1
+    tdt = {8: torch.uint8, 16: torch.int16, 32: torch.int32}[bits]
+    wrap = torch.where(img >= (1 << (bits - 1)), img - (1 << bits), img) if bits > 8 else img
+    keys = wrap.to(tdt).contiguous()
+    if kt == "i8":
+        keys = keys.view(torch.int8)
+    elif kt == "bool":
+        keys = keys.view(torch.bool)
+    order_img = img ^ (1 << (bits - 1)) if kt in ("i8", "i16", "i32") else img
+    desc = bool(rng.random() < 0.4)
+    begin, end = (0, bits) if rng.random() < 0.5 else (lambda b: (b, int(rng.integers(b, bits + 1))))(int(rng.integers(0, bits)))
+    width = end - begin
+    d = (order_img >> begin) & ((1 << width) - 1) if width > 0 else torch.zeros_like(order_img)
+    if desc and width > 0:
+        d = ((1 << width) - 1) - d
+    perm = torch.sort(d, stable=True)[1]
+    vals = None
+    if vb:
+        vals = {1: lambda: torch.randint(0, 256, (n,), device=dev, generator=g).to(torch.uint8),
+                2: lambda: torch.randint(-2**15, 2**15, (n,), device=dev, generator=g).to(torch.int16),
+                4: lambda: torch.arange(n, dtype=torch.int32, device=dev),
+                8: lambda: torch.arange(n, dtype=torch.int64, device=dev) * 0x100000001,
+                16: lambda: torch.randint(-2**31, 2**31 - 1, (n, 4), device=dev, generator=g).to(torch.int32)}[vb]()
+    case = dict(it=it, algo="any", n=n, kt=kt, vb=vb, desc=desc, begin=begin, end=end, seed=seed)
+    dk = gs.DoubleBuffer(keys.clone(), torch.zeros_like(keys))
+    dv = gs.DoubleBuffer(vals.clone(), torch.zeros_like(vals)) if vb else None
+    R = gs.DeviceRadixSort
+    fn = (R.SortPairsDescending if desc else R.SortPairs) if vb else (R.SortKeysDescending if desc else R.SortKeys)
+    args = (dk, dv, n) if vb else (dk, n)
+    nb = fn(None, 0, *args, key_type=gtype)
+    temp = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+    fn(temp, nb, *args, begin, end, key_type=gtype)
+    if n == 0:
+        return
+    if not torch.equal(dk.Current().view(torch.uint8), keys[perm].contiguous().view(torch.uint8)):
+        fail("any keys", **case)
+    if vb and not torch.equal(dv.Current(), vals[perm]):
+        fail("any values (stability)", **case)
+
+
 def shard_case(it):
     """The multi-GPU pipeline's kernels with every rank emulated in this process: gs_msb_first_pass_u32 on W random
     shards, the host's split / group maps, then for one random rank the receive buffer it would get (group-major,
@@ -248,7 +303,11 @@ def shard_case(it):
 KINDS = ["uniform", "and1", "and3", "and6", "and10", "few", "const", "ones_heavy", "sorted", "reverse", "low_bytes", "hot"]
 counts = {}
 for it in range(iters):
-    algo = str(rng.choice(["lsb", "lsb", "msb", "msb", "seg", "wide"]))
+    algo = str(rng.choice(["lsb", "lsb", "msb", "msb", "seg", "wide", "any"]))
+    if algo == "any":
+        counts[algo] = counts.get(algo, 0) + 1
+        any_case(it)
+        continue
     if algo == "wide":
         counts[algo] = counts.get(algo, 0) + 1
         wide_case(it)
