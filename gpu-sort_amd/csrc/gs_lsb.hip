@@ -24,6 +24,12 @@
 //             blocks that each own a long run of tiles and march in lockstep.
 #include "gs_device.hpp"
 #include "gs_lsb.hpp"
+#ifndef GS_EXP_SLEEP_MODE
+#define GS_EXP_SLEEP_MODE 0
+#endif
+#ifndef GS_EXP_SLEEP_PAIRS
+#define GS_EXP_SLEEP_PAIRS 0
+#endif
 #include <cstdlib>
 #include <cstring>
 
@@ -408,6 +414,9 @@ __device__ __forceinline__ void downsweep_tile(DownsweepSmem<HAS_VALUES> &sm, co
 #endif
     // keys only: the waves that issue loads and stores get priority over the ones that rank, so the memory
     // pipes are fed as early as possible (1.87 -> 1.82 ms; with values it costs 7 %, so pairs keep the default)
+#ifdef GS_EXP_SLEEP_START
+    __builtin_amdgcn_s_sleep(GS_EXP_SLEEP_START);
+#endif
     if (!HAS_VALUES) __builtin_amdgcn_s_setprio(3);
     const uint64_t tile_base = (uint64_t)t * LSB_TILE;
     const uint32_t valid = TAIL ? tail_valid : (uint32_t)LSB_TILE;
@@ -643,6 +652,28 @@ __device__ __forceinline__ void downsweep_tile(DownsweepSmem<HAS_VALUES> &sm, co
     GS_PHASE(5);                                   // LDS scatter
     __syncthreads();
     GS_PHASE(6);                                   // barrier 3
+    // Pacing (round 3, in-process A/B on the same buffers, tools/ab_inproc.py): half of the waves start their 16 stores 32 x 64 cycles
+    // (~0.9 us) after the others, so the workgroup's 128 store instructions do not leave in one burst: 1.803 -> 1.748 ms and
+    // 1.790 -> 1.763 ms per launch on two placements of the arrays (all waves pausing 28: 1.762; a pause that grows with the
+    // wave index, or one at the workgroup's start: slower).  profiles/r03_lsb_floor.md has the mechanism: a burst of partial-line
+    // writes makes the halves of a line arrive further apart.  GS_EXP_SLEEP* override it for experiments.
+#ifndef GS_EXP_SLEEP
+#define GS_EXP_SLEEP 32
+#define GS_EXP_SLEEP_MODE_DEFAULT 1
+#else
+#define GS_EXP_SLEEP_MODE_DEFAULT GS_EXP_SLEEP_MODE
+#endif
+    if (!HAS_VALUES || GS_EXP_SLEEP_PAIRS) {
+#if GS_EXP_SLEEP_MODE_DEFAULT == 3
+        if (w & 1) __builtin_amdgcn_s_sleep(GS_EXP_SLEEP); else __builtin_amdgcn_s_sleep(GS_EXP_SLEEP_B);
+#elif GS_EXP_SLEEP_MODE_DEFAULT == 4
+        if (w >= 4) __builtin_amdgcn_s_sleep(GS_EXP_SLEEP);
+#elif GS_EXP_SLEEP_MODE_DEFAULT == 1
+        if (w & 1) __builtin_amdgcn_s_sleep(GS_EXP_SLEEP);
+#elif GS_EXP_SLEEP_MODE_DEFAULT == 0
+        __builtin_amdgcn_s_sleep(GS_EXP_SLEEP);
+#endif
+    }
     if (!HAS_VALUES) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int i = 0; i < LSB_KPT; ++i) {

@@ -1,0 +1,53 @@
+"""A/B of library builds INSIDE one process on the SAME buffers (the placement of the arrays changes a kernel's time by several
+percent from one allocation to the next, profiles/README.md round 3): every build is loaded with ctypes and runs the LSB sort of
+2^30 keys (or pairs) alternately, per-kernel times from each build's own event hook.
+python tools/ab_inproc.py [pairs] libA.so libB.so ...   (names inside gpu-sort_amd/lib)"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import gpu_sort_amd as gs
+args = sys.argv[1:]
+pairs = bool(args) and args[0] == "pairs"
+if pairs:
+    args = args[1:]
+libdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-sort_amd", "lib")
+dev = torch.device("cuda:0")
+n = 1 << 30
+src = gs.generate_uniform_keys(n, device=dev)
+a, b = torch.empty_like(src), torch.empty_like(src)
+va = gs.generate_enumerated_values(n, device=dev) if pairs else None
+vb = torch.empty_like(src) if pairs else None
+nb = gs.lib.gs_lsb_temp_bytes(n, int(pairs))
+temp = torch.empty(nb, dtype=torch.uint8, device=dev)
+libs = []
+for name in args:
+    L = C.CDLL(os.path.join(libdir, name))
+    L.gs_profile_create.restype = C.c_void_p
+    L.gs_lsb_sort_u32.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.gs_profile_begin.argtypes = [C.c_void_p]
+    L.gs_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    libs.append((name, L, C.c_void_p(L.gs_profile_create())))
+res = {f"{i}:{name}": [] for i, (name, _, _) in enumerate(libs)}
+stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+for rnd in range(5):
+    for i, (name, L, prof) in enumerate(libs):
+        a.copy_(src)
+        if pairs:
+            gs.generate_enumerated_values(n, device=dev, out=va)
+        keys = (C.c_void_p * 2)(a.data_ptr(), b.data_ptr())
+        vals = (C.c_void_p * 2)(va.data_ptr(), vb.data_ptr()) if pairs else None
+        sel = C.c_int(0)
+        ms0, c0 = (C.c_double * 10)(), (C.c_uint64 * 10)()
+        L.gs_profile_read(prof, ms0, c0)
+        L.gs_profile_begin(prof)
+        e = L.gs_lsb_sort_u32(temp.data_ptr(), nb, keys, vals, C.byref(sel), n, 0, 32, 0, 0, stream)
+        L.gs_profile_end()
+        assert e == 0, e
+        torch.cuda.synchronize()
+        ms1, c1 = (C.c_double * 10)(), (C.c_uint64 * 10)()
+        L.gs_profile_read(prof, ms1, c1)
+        if rnd:
+            res[f"{i}:{name}"].append(((ms1[0] - ms0[0]) / 4, (ms1[2] - ms0[2]) / 4))
+for name, v in res.items():
+    ups = sorted(x[0] for x in v); dss = sorted(x[1] for x in v)
+    print(f"{name:28s} upsweep median {ups[len(ups)//2]:.4f}  downsweep median {dss[len(dss)//2]:.4f} min {dss[0]:.4f} max {dss[-1]:.4f} ms/launch", flush=True)
