@@ -37,7 +37,8 @@ namespace gs {
 
 // ---------------------------------------------------------------- upsweep --
 #ifndef UPSWEEP_BATCH
-#define UPSWEEP_BATCH 32   // dword loads in flight per lane (a tile is 128 per lane)
+#define UPSWEEP_BATCH 64   // dword loads in flight per lane (a tile is 128 per lane).  In-process A/B at 2^30 keys (round 3, tools/ab_inproc.py):
+                           // 16 -> 0.751 ms, 32 -> 0.709-0.721, 64 -> 0.685-0.694, 128 -> 0.707 ms per launch (64: 150 VGPRs, one workgroup per CU)
 #endif
 #ifndef UPSWEEP_SUB
 #define UPSWEEP_SUB 4      // histogram copies per wave (power of two)
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
     }
 #endif
     if (!TAIL && blockIdx.x >= full_tiles) return;   // (n_ is preloaded: two scalar instructions, no memory wait)
-    const uint32_t t = TAIL ? full_tiles : tile_of_item(blockIdx.x, full_tiles);
+    const uint32_t t = TAIL ? full_tiles : tile_of_item_wide(blockIdx.x, full_tiles);
     downsweep_tile<HAS_VALUES, TAIL, TW, BIG, false>(sm, t, keys_in, keys_out, vals_in, vals_out, spine, prefix16, totals, p,
                                                      nullptr, 0u, nullptr);
 }

@@ -45,6 +45,27 @@ __device__ __forceinline__ uint32_t tile_of_item(uint32_t i, uint32_t full_tiles
     return base + (r % MI355X_XCDS) * (LSB_RESIDENT / MI355X_XCDS) + r / MI355X_XCDS;
 }
 
+// The same with groups as large as the array allows (the three-launch LSB downsweep, round 3): groups of 2^k items, k <= 13, the
+// remainder cut into smaller powers of two the same way, so that arrays of any size keep XCD-contiguous slices.  In-process A/B
+// on the same buffers at 2^30 keys (tools/ab_inproc.py): groups of 256 items 1.810 ms, 512 1.766-1.775, 1024 1.781, 2048 1.792,
+// 4096 1.772, 8192 1.758, 32768 1.764, all items 1.743-1.756 ms per launch: slices of >= 1024 consecutive tiles per XCD are worth 1 %.
+constexpr uint32_t LSB_WIDE_GROUP = 8192;
+__device__ __forceinline__ uint32_t tile_of_item_wide(uint32_t i, uint32_t full_tiles)
+{
+    uint32_t base = 0, rem = full_tiles;
+    for (;;) {
+        const uint32_t G = rem >= LSB_WIDE_GROUP ? LSB_WIDE_GROUP : (1u << (31u - (uint32_t)__builtin_clz(rem | 1u)));
+        if (G < 2u * MI355X_XCDS) return i;                 // a handful of tiles: identity
+        const uint32_t span = (rem / G) * G;                // whole groups of this size
+        if (i < base + span) {
+            const uint32_t r = (i - base) % G;
+            return i - r + (r % MI355X_XCDS) * (G / MI355X_XCDS) + r / MI355X_XCDS;
+        }
+        base += span; rem -= span;
+        if (rem == 0) return i;                             // (i >= full_tiles: not a tile; callers guard)
+    }
+}
+
 // Upsweep block i -> chunk: inside every group of LSB_UPSWEEP_GROUP blocks the blocks of one XCD take consecutive
 // chunks (their totals are neighbours in the spine rows).  Speed only.
 constexpr uint32_t LSB_UPSWEEP_GROUP = 256;
