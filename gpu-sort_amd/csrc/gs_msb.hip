@@ -321,7 +321,10 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int 
     const uint32_t nchunks = ntiles / MSB_WAVES + 1;          // covers tile index `ntiles` too (see classify)
     const int tid = threadIdx.x, w = wave_id(), lane = lane_id();
     uint32_t *my = lh[w][lane & (SUB - 1)];
-    constexpr int BATCH = 32;
+#ifndef GS_MSB_UPS_BATCH
+#define GS_MSB_UPS_BATCH 32
+#endif
+    constexpr int BATCH = GS_MSB_UPS_BATCH;
     for (uint32_t c0 = blockIdx.x; c0 < nchunks; c0 += gridDim.x) {
         // the blocks of one XCD take consecutive chunks: neighbours in the spine rows meet in one L2 (see lsb_upsweep_kernel;
         // a block that loops strides by MSB_MAX_GRID, a multiple of 8, so it stays on its residue class)
@@ -342,7 +345,32 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int 
                     n_less += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(k < cand));
                 }
             };
-            if (T.valid == (uint32_t)MSB_TILE) {
+            if (!REMAP && T.valid == (uint32_t)MSB_TILE && !(PIVOT && examine)) {
+                // full tile, plain digit, no heavy-hitter tallies (nearly every tile of a level): the lean path of the LSB upsweep --
+                // no per-key test for a digit shared by the whole wave (made on two keys of the batch instead), 4 vector
+                // instructions per key instead of 15
+                uint32_t wbits = (uint32_t)ds.bits;
+                asm volatile("" : "+v"(wbits));
+                auto digit_of = [&](uint32_t raw) {
+                    return __builtin_amdgcn_ubfe(ds.tw_in ? twiddle_in(raw, ds.f32_in, ds.xor_in) : raw, (uint32_t)ds.shift, wbits);
+                };
+#pragma unroll 1
+                for (int j = 0; j < MSB_TILE / WAVE; j += BATCH) {
+                    uint32_t v[BATCH];
+#pragma unroll
+                    for (int u = 0; u < BATCH; ++u) v[u] = __builtin_nontemporal_load(&p[(j + u) * WAVE + lane]);
+                    const uint32_t da = digit_of(v[0]), db = digit_of(v[BATCH / 2]);
+                    const bool hot = __builtin_amdgcn_ballot_w64(da == __builtin_amdgcn_readfirstlane(da)) == ~0ull ||
+                                     __builtin_amdgcn_ballot_w64(db == __builtin_amdgcn_readfirstlane(db)) == ~0ull;
+                    if (hot) {
+#pragma unroll
+                        for (int u = 0; u < BATCH; ++u) hist_add(my, digit_of(v[u]));
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < BATCH; ++u) atomicAdd(&my[digit_of(v[u])], 1u);
+                    }
+                }
+            } else if (T.valid == (uint32_t)MSB_TILE) {
 #pragma unroll
                 for (int j = 0; j < MSB_TILE / WAVE; j += BATCH) {
                     uint32_t v[BATCH];
@@ -777,6 +805,10 @@ __device__ __forceinline__ void msb_scatter_tile(ScatterSmem<HAS_VALUES, REMAP> 
         }
     }
     __syncthreads();
+#ifndef GS_MSB_SCATTER_SLEEP
+#define GS_MSB_SCATTER_SLEEP 0
+#endif
+    if (!HAS_VALUES && GS_MSB_SCATTER_SLEEP && (w & 1)) __builtin_amdgcn_s_sleep(GS_MSB_SCATTER_SLEEP);   // see lsb_downsweep_kernel
     if (!HAS_VALUES) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int i = 0; i < MSB_KPT; ++i) {
@@ -880,7 +912,11 @@ __global__ __launch_bounds__(MSB_THREADS, HAS_VALUES ? 4 : 6) void msb_scatter_k
     uint32_t g;
     if (FULL) {
         if (blockIdx.x >= (uint32_t)packed) return;
+#ifdef GS_MSB_WIDE_GROUP
+        g = tile_of_item_wide(blockIdx.x, (uint32_t)packed);
+#else
         g = tile_of_item(blockIdx.x, (uint32_t)packed);   // neighbouring tiles on one XCD: their runs meet in one L2
+#endif
     } else if (ragged_anywhere) {                         // buckets in pieces: one block per tile, full ones skipped
         if (blockIdx.x >= (uint32_t)packed) return;
         g = blockIdx.x;
