@@ -27,6 +27,9 @@
 #ifndef GS_EXP_SLEEP_MODE
 #define GS_EXP_SLEEP_MODE 0
 #endif
+#ifndef GS_EXP_SLEEP_MIN_TILES
+#define GS_EXP_SLEEP_MIN_TILES 49152u
+#endif
 #ifndef GS_EXP_SLEEP_PAIRS
 #define GS_EXP_SLEEP_PAIRS 0
 #endif
@@ -204,8 +207,11 @@ __device__ __forceinline__ void upsweep_chunk(UpsweepSmem<NEXT, PIPE> &sm, const
     }
 }
 
+#ifndef GS_EXP_UPS_WPE
+#define GS_EXP_UPS_WPE 1
+#endif
 template <bool NEXT, bool PLAIN = false>
-__global__ __launch_bounds__(LSB_THREADS) void lsb_upsweep_kernel(const uint32_t *__restrict__ keys,
+__global__ __launch_bounds__(LSB_THREADS, GS_EXP_UPS_WPE) void lsb_upsweep_kernel(const uint32_t *__restrict__ keys,
                                                                   uint32_t *__restrict__ spine,
                                                                   uint16_t *__restrict__ prefix16,
                                                                   uint32_t *__restrict__ next_totals, PassParams p, PipeParams q)
@@ -451,7 +457,10 @@ __device__ __forceinline__ void downsweep_tile(DownsweepSmem<HAS_VALUES> &sm, co
         }
     }
     GS_PHASE(0);                                   // load issue
-    if (!HAS_VALUES) __builtin_amdgcn_s_setprio(0);
+#ifndef GS_EXP_RANK_PRIO
+#define GS_EXP_RANK_PRIO 0
+#endif
+    if (!HAS_VALUES) __builtin_amdgcn_s_setprio(GS_EXP_RANK_PRIO);
     if (HAS_VALUES) {
         const uint32_t *vin = vals_in + tile_base;
 #pragma unroll
@@ -653,29 +662,39 @@ __device__ __forceinline__ void downsweep_tile(DownsweepSmem<HAS_VALUES> &sm, co
     GS_PHASE(5);                                   // LDS scatter
     __syncthreads();
     GS_PHASE(6);                                   // barrier 3
-    // Pacing (round 3, in-process A/B on the same buffers, tools/ab_inproc.py): half of the waves start their 16 stores 32 x 64 cycles
-    // (~0.9 us) after the others, so the workgroup's 128 store instructions do not leave in one burst: 1.803 -> 1.748 ms and
-    // 1.790 -> 1.763 ms per launch on two placements of the arrays (all waves pausing 28: 1.762; a pause that grows with the
-    // wave index, or one at the workgroup's start: slower).  profiles/r03_lsb_floor.md has the mechanism: a burst of partial-line
-    // writes makes the halves of a line arrive further apart.  GS_EXP_SLEEP* override it for experiments.
+    // Pacing (round 3, in-process A/B on the same buffers, tools/ab_inproc.py): every wave pauses 32 x 64 cycles (~0.9 us) between
+    // barrier 3 and its 16 stores.  What it buys depends on where the driver placed the arrays: on placements where the kernel
+    // runs 1.89-1.94 ms per launch without the pause it runs 1.78-1.79 ms with it; on placements where it runs 1.74 ms without,
+    // the pause costs 0.7-1.5 % (1.755-1.77 ms) -- profiles/r03_ab_pacing.txt has both kinds, from the same box and process
+    // sequence.  So the pause takes 8 % off the slow placements and the spread between placements shrinks from 11 % to 2 %.
+    // Pauses of 8/16/24 recover less of the slow case (1.91/1.88/1.81 ms), 40-64 cost more of the fast one; pausing only the odd
+    // waves (behind a scalar branch) 1.85 ms.  Only from 2^29 keys up: below, the launch is not bound by the memory system
+    // and the pause is latency (2^28 keys: +1 %; 2^22-2^24: +5 %).  Pairs gain nothing from it (3.57-3.62 ms with 16/32, 3.71 with
+    // 64, 3.58-3.60 without).  GS_EXP_SLEEP* override all of it for experiments.
 #ifndef GS_EXP_SLEEP
 #define GS_EXP_SLEEP 32
-#define GS_EXP_SLEEP_MODE_DEFAULT 1
+#define GS_EXP_SLEEP_MODE_DEFAULT 0
 #else
 #define GS_EXP_SLEEP_MODE_DEFAULT GS_EXP_SLEEP_MODE
 #endif
-    if (!HAS_VALUES || GS_EXP_SLEEP_PAIRS) {
+    if ((!HAS_VALUES || GS_EXP_SLEEP_PAIRS) && full_tiles >= GS_EXP_SLEEP_MIN_TILES) {
+        // s_sleep is a scalar instruction: it must sit behind a SCALAR branch (a branch on a vector condition only masks lanes
+        // and the wave sleeps all the same), hence the readfirstlane
+        [[maybe_unused]] const int ws = __builtin_amdgcn_readfirstlane(w);
 #if GS_EXP_SLEEP_MODE_DEFAULT == 3
-        if (w & 1) __builtin_amdgcn_s_sleep(GS_EXP_SLEEP); else __builtin_amdgcn_s_sleep(GS_EXP_SLEEP_B);
+        if (ws & 1) __builtin_amdgcn_s_sleep(GS_EXP_SLEEP); else __builtin_amdgcn_s_sleep(GS_EXP_SLEEP_B);
 #elif GS_EXP_SLEEP_MODE_DEFAULT == 4
-        if (w >= 4) __builtin_amdgcn_s_sleep(GS_EXP_SLEEP);
+        if (ws >= 4) __builtin_amdgcn_s_sleep(GS_EXP_SLEEP);
 #elif GS_EXP_SLEEP_MODE_DEFAULT == 1
-        if (w & 1) __builtin_amdgcn_s_sleep(GS_EXP_SLEEP);
+        if (ws & 1) __builtin_amdgcn_s_sleep(GS_EXP_SLEEP);
 #elif GS_EXP_SLEEP_MODE_DEFAULT == 0
         __builtin_amdgcn_s_sleep(GS_EXP_SLEEP);
 #endif
     }
-    if (!HAS_VALUES) __builtin_amdgcn_s_setprio(3);
+#ifndef GS_EXP_STORE_PRIO
+#define GS_EXP_STORE_PRIO 3
+#endif
+    if (!HAS_VALUES) __builtin_amdgcn_s_setprio(GS_EXP_STORE_PRIO);
 #pragma unroll
     for (int i = 0; i < LSB_KPT; ++i) {
         // a wave stores 1024 CONSECUTIVE slots (not every 512th 64-slot group): its 16 store instructions walk ~32
@@ -758,7 +777,11 @@ __global__ __launch_bounds__(LSB_THREADS, HAS_VALUES ? 4 : 6) void lsb_downsweep
     }
 #endif
     if (!TAIL && blockIdx.x >= full_tiles) return;   // (n_ is preloaded: two scalar instructions, no memory wait)
+#ifdef GS_EXP_WIDE_MIN_TILES
+    const uint32_t t = TAIL ? full_tiles : full_tiles < GS_EXP_WIDE_MIN_TILES ? tile_of_item(blockIdx.x, full_tiles) : tile_of_item_wide(blockIdx.x, full_tiles);
+#else
     const uint32_t t = TAIL ? full_tiles : tile_of_item_wide(blockIdx.x, full_tiles);
+#endif
     downsweep_tile<HAS_VALUES, TAIL, TW, BIG, false>(sm, t, keys_in, keys_out, vals_in, vals_out, spine, prefix16, totals, p,
                                                      nullptr, 0u, nullptr);
 }

@@ -68,7 +68,10 @@ __device__ __forceinline__ uint32_t tile_of_item_wide(uint32_t i, uint32_t full_
 
 // Upsweep block i -> chunk: inside every group of LSB_UPSWEEP_GROUP blocks the blocks of one XCD take consecutive
 // chunks (their totals are neighbours in the spine rows).  Speed only.
-constexpr uint32_t LSB_UPSWEEP_GROUP = 256;
+#ifndef GS_EXP_UPS_GROUP
+#define GS_EXP_UPS_GROUP 256
+#endif
+constexpr uint32_t LSB_UPSWEEP_GROUP = GS_EXP_UPS_GROUP;
 __device__ __forceinline__ uint32_t chunk_of_block(uint32_t b, uint32_t grid)
 {
     const uint32_t base = (b / LSB_UPSWEEP_GROUP) * LSB_UPSWEEP_GROUP;

@@ -14,7 +14,7 @@ pairs = mode == "pairs"
 msb = mode.startswith("msb")
 libdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-sort_amd", "lib")
 dev = torch.device("cuda:0")
-n = 1 << 30
+n = 1 << int(os.environ.get('LOG2N', '30'))
 src = (gs.generate_zipf_keys if mode == "msbzipf" else gs.generate_uniform_keys)(n, device=dev)
 a, b = torch.empty_like(src), torch.empty_like(src)
 va = gs.generate_enumerated_values(n, device=dev) if pairs else None
