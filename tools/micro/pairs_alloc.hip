@@ -13,7 +13,8 @@ int main(int argc, char **argv)
 {
     const int log2n = argc > 1 ? atoi(argv[1]) : 30, trials = argc > 2 ? atoi(argv[2]) : 5;
     const bool keys_only = argc > 3 && argv[3][0] == 'k';
-    const uint64_t n = 1ull << log2n;
+    // argv[1] > 64: the number of keys itself (a count that is no power of two puts the digit streams at an odd spacing)
+    const uint64_t n = log2n > 64 ? (uint64_t)atoll(argv[1]) : 1ull << log2n;
     const size_t tb = gs_lsb_temp_bytes(n, 1);
     void *temp;
     CK(hipMalloc(&temp, tb));
@@ -47,7 +48,7 @@ int main(int argc, char **argv)
                 const double ds = (ms[GS_K_LSB_DOWNSWEEP] - last_ds) / (double)(cnt[GS_K_LSB_DOWNSWEEP] - last_dc);
                 const double us = (ms[GS_K_LSB_UPSWEEP] - last_us) / (double)(cnt[GS_K_LSB_UPSWEEP] - last_uc);
                 last_ds = ms[GS_K_LSB_DOWNSWEEP]; last_dc = cnt[GS_K_LSB_DOWNSWEEP]; last_us = ms[GS_K_LSB_UPSWEEP]; last_uc = cnt[GS_K_LSB_UPSWEEP];
-                printf("trial %d  %-10s  %s downsweep %.3f ms  upsweep %.3f ms\n", t, mode ? "contiguous" : "hipMalloc", keys_only ? "keys " : "pairs", ds, us);
+                printf("trial %d  %-10s  %s downsweep %.3f ms  upsweep %.3f ms   (%.4f / %.4f ns per Ki keys)\n", t, mode ? "contiguous" : "hipMalloc", keys_only ? "keys " : "pairs", ds, us, ds * 1e6 / (double)n * 1024, us * 1e6 / (double)n * 1024);
                 fflush(stdout);
             }
         next:
