@@ -1017,6 +1017,21 @@ struct LocalSmem {
 // `pad` word; LS_FLAGGED = the general plan for the flagged tasks.  The MSB sort launches LS_ONEPASS then
 // LS_FLAGGED per class: two lean kernels instead of one that holds both plans (and spills at 64 VGPRs).
 enum { LS_ALL = 0, LS_ONEPASS = 1, LS_FLAGGED = 2 };
+#ifdef GS_EXP_LS_PHASES
+// experiment builds only (tools/ls_phases.py): shader-clock length of every phase of wave 0, per task; [plan][class][task][16]
+constexpr uint32_t LSP_TASKS = 65536;
+__device__ uint32_t gs_ls_phase_buf[2 * MSB_NCLASS * LSP_TASKS * 16];
+#define LSP(k)                                                                                                         \
+    do {                                                                                                               \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                  \
+        if (tid == 0 && ti < LSP_TASKS) gs_ls_phase_buf[(((MODE == LS_ONEPASS ? 0 : 1) * MSB_NCLASS + cls) * LSP_TASKS + ti) * 16 + (k)] += (uint32_t)(now_ - tprev_); \
+        tprev_ = now_;                                                                                                 \
+    } while (0)
+#define LSP_WAIT(what) asm volatile("s_waitcnt " what ::: "memory")
+#else
+#define LSP(k) do { } while (0)
+#define LSP_WAIT(what) do { } while (0)
+#endif
 constexpr uint32_t LS_FLAG = 0x80000000u;
 // PLAIN: no key transform on the way in or out (u32 ascending): instantiated for the one-pass kernels, where it is 9 of ~30
 // vector instructions per key.
@@ -1101,9 +1116,16 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
     request(T);
     [[maybe_unused]] bool zeroed = false;   // LS_ONEPASS: the staging buffer holds zeros (cleared by the store phase)
     for (;;) {
+#ifdef GS_EXP_LS_PHASES
+        unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+        const unsigned long long t0_ = tprev_, r0_ = __builtin_amdgcn_s_memrealtime();
+#endif
         MsbTask Tn = T;
         const uint32_t tn = advance(ti + gridDim.x, Tn);
         const bool has_next = tn < ntasks;
+        LSP(0);                                           // next task record
+        LSP_WAIT("vmcnt(0)");
+        LSP(1);                                           // wait for this task's keys
         {
             const uint32_t wbase = fresh(wbase0);
 #pragma unroll
@@ -1130,6 +1152,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                 __syncthreads();
             }
             zeroed = false;
+            LSP(2);                                       // (first task of the block) zero the counters
             uint32_t overflow = 0;
             {
                 const uint32_t wbase = fresh(wbase0);
@@ -1176,7 +1199,11 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                     overflow = (rmax >= 255u) ? 1u : 0u;
                 }
             }
-            if (!__syncthreads_or((int)overflow)) {
+            LSP_WAIT("lgkmcnt(0)");
+            LSP(3);                                       // counting: one fetch-add per key
+            const int ovf_ = __syncthreads_or((int)overflow);
+            LSP(4);                                       // barrier
+            if (!ovf_) {
                 // exclusive scan of the word sums, written over the words (WPT consecutive words per thread).  A scanned word
                 // keeps its four counts next to its base -- {base : 16, four 4-bit counts : 16} -- so that ONE more LDS read per
                 // key yields both the word's base and the keys of the lower bins of the same word (a read of the raw counts
@@ -1210,7 +1237,9 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                 }
                 const uint32_t inc = wave_inclusive_scan(ssum);
                 if (lane == 63) sm.wtot[w] = inc;
+                LSP(5);                                   // word sums + wave scan
                 __syncthreads();
+                LSP(6);                                   // barrier
                 const uint32_t wsv = (lane < WAVES) ? sm.wtot[lane] : 0u;
                 const uint32_t wincl = wave_inclusive_scan(wsv);
                 uint32_t run = (uint32_t)__shfl((int)(wincl - wsv), w, WAVE) + inc - ssum;
@@ -1232,7 +1261,11 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                         *p4 = e4;
                     }
                 }
-                if (!__syncthreads_or((int)(wide != 0u))) {
+                LSP_WAIT("lgkmcnt(0)");
+                LSP(7);                                   // bases written over the words
+                const int wide_ = __syncthreads_or((int)(wide != 0u));
+                LSP(8);                                   // barrier
+                if (!wide_) {
 #pragma unroll
                 for (int i = 0; i < KPT; ++i) {
                     const uint32_t wd = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(sm.hist) + (key[i] & wmask));
@@ -1241,7 +1274,9 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                 }
 #pragma unroll
                 for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]));
+                LSP(9);                                   // one lookup per key
                 __syncthreads();                          // the counters are dead: the buffer takes the keys
+                LSP(10);                                  // barrier
                 {
                     // no guards: a pad goes to its own load slot, which lies behind the real keys
                     const uint32_t wbase = fresh(wbase0);
@@ -1253,7 +1288,10 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                         else sm.stage[at] = key[i];
                     }
                 }
+                LSP_WAIT("lgkmcnt(0)");
+                LSP(11);                                  // keys into the staging buffer
                 __syncthreads();
+                LSP(12);                                  // barrier
                 done = true;
                 }
             }
@@ -1268,6 +1306,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
             const uint32_t nbins = 1u << b1, mask1 = nbins - 1u;
             for (uint32_t j = tid; j < nbins; j += THREADS) sm.hist[j] = 0;
             __syncthreads();
+            LSP(2);                                       // zero the histogram + barrier
             // the pads take no part in this pass (an order-free rank could put one in front of a real key
             // with all-ones digits): real keys fill [0, size), the pads stay implicit behind them
             {
@@ -1292,7 +1331,10 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
             }
 #pragma unroll
             for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]), "+v"(key[i]));
+            LSP_WAIT("lgkmcnt(0)");
+            LSP(3);                                       // first pass: fetch-adds
             __syncthreads();
+            LSP(4);                                       // barrier
             // exclusive scan of the bins in place: IPT consecutive bins per thread (fewer bins: fewer threads)
             constexpr uint32_t IPT = (1u << LOCAL_B1) / THREADS;
             const bool act = (uint32_t)tid * IPT < nbins;
@@ -1321,12 +1363,17 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                     *p4 = e4;
                 }
             }
+            LSP_WAIT("lgkmcnt(0)");
+            LSP(5);                                       // scan of the bins (one barrier inside)
             __syncthreads();
+            LSP(6);                                       // barrier
 #pragma unroll
             for (int i = 0; i < KPT; ++i) pos[i] += sm.hist[key[i] & mask1];
 #pragma unroll
             for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]));
+            LSP(7);                                       // base lookup
             __syncthreads();                              // the histogram is dead: the buffer takes the keys
+            LSP(8);                                       // barrier
             {
                 const uint32_t wbase = fresh(wbase0);
 #pragma unroll
@@ -1337,7 +1384,10 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                     }
                 }
             }
+            LSP_WAIT("lgkmcnt(0)");
+            LSP(9);                                       // keys into the staging buffer
             __syncthreads();
+            LSP(10);                                      // barrier
         }
         // ---- remaining bits: stable passes of <= 8 bits
         uint32_t rem = B - b1, np = (rem + 7u) / 8u, shift = b1 + (STABLE ? T.pad : 0u);
@@ -1429,9 +1479,11 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
             __syncthreads();
             shift += b; rem -= b; --np;
         }
+        LSP(11);                                          // the stable passes, all of them
         }   // general plan
         // ---- request the next task's keys, then store this one from the buffer
         if (has_next) request(Tn);
+        LSP(13);                                          // request the next task's keys
         if (done) {
         uint32_t *qk = dst_k + T.offset, *qv = HAS_VALUES ? dst_v + T.offset : nullptr;
         if (HAS_VALUES) {
@@ -1458,7 +1510,14 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
             }
         }
         }   // done
+        LSP(14);                                          // read the buffer, issue the stores
         __syncthreads();
+#ifdef GS_EXP_LS_PHASES
+        if (tid == 0 && ti < LSP_TASKS) {                  // [15]: the task's whole time in shader clocks, barrier included
+            gs_ls_phase_buf[(((MODE == LS_ONEPASS ? 0 : 1) * MSB_NCLASS + cls) * LSP_TASKS + ti) * 16 + 15] += (uint32_t)(__builtin_amdgcn_s_memtime() - t0_);
+            (void)r0_;
+        }
+#endif
         if (!has_next) break;
         T = Tn; ti = tn;
     }
@@ -2546,6 +2605,16 @@ int gs_msb_classify_upto(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint
                          stop_level, (flags & 1) == 0);
 }
 
+#ifdef GS_EXP_LS_PHASES
+// out == nullptr: clear the stamps; otherwise copy all of them out ([plan][class][task][16] words)
+int gs_exp_ls_phases(uint32_t *out)
+{
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(gs_ls_phase_buf)) != hipSuccess) return (int)hipGetLastError();
+    if (!out) return (int)hipMemset(p, 0, sizeof(uint32_t) * 2 * MSB_NCLASS * LSP_TASKS * 16);
+    return (int)hipMemcpy(out, p, sizeof(uint32_t) * 2 * MSB_NCLASS * LSP_TASKS * 16, hipMemcpyDeviceToHost);
+}
+#endif
 #ifdef GS_EXP_CLS
 int gs_exp_cls_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gs_cls_stamp), sizeof(unsigned long long) * 16 * 8); }
 #endif

@@ -15,6 +15,14 @@ msb = mode.startswith("msb")
 libdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpu-sort_amd", "lib")
 dev = torch.device("cuda:0")
 n = 1 << int(os.environ.get('LOG2N', '30'))
+# CHURN=k: perturb where the arrays land (a fresh process usually gets a "fast" placement): k rounds of odd-sized allocations, every
+# other one freed again (with empty_cache, so the driver gets the memory back) before the arrays are allocated
+hold = []
+for r in range(int(os.environ.get("CHURN", "0"))):
+    tmp = [torch.empty(int((0.3 + 0.37 * ((7 * r + 3 * j) % 11)) * 2**30), dtype=torch.uint8, device=dev) for j in range(8)]
+    hold += tmp[::2]
+    del tmp
+    torch.cuda.empty_cache()
 src = (gs.generate_zipf_keys if mode == "msbzipf" else gs.generate_uniform_keys)(n, device=dev)
 a, b = torch.empty_like(src), torch.empty_like(src)
 va = gs.generate_enumerated_values(n, device=dev) if pairs else None

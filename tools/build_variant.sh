@@ -4,6 +4,7 @@
 name="$1"; flags="$2"
 cd "$(dirname "$0")/../gpu-sort_amd/csrc" || exit 1
 obj=/tmp/gs_variant_$name; mkdir -p $obj
+rm -f $obj/*.o          # a failed compile must not link a stale object
 for f in *.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wno-unused-result -Wno-unused-value $flags -c $f -o $obj/${f%.hip}.o &
 done
