@@ -1016,15 +1016,64 @@ struct LocalSmem {
 // sort (see below), tasks it cannot take (too many bits, or a bin that reaches 255 keys) are flagged in their
 // `pad` word; LS_FLAGGED = the general plan for the flagged tasks.  The MSB sort launches LS_ONEPASS then
 // LS_FLAGGED per class: two lean kernels instead of one that holds both plans (and spills at 64 VGPRs).
-enum { LS_ALL = 0, LS_ONEPASS = 1, LS_FLAGGED = 2 };
+enum { LS_ALL = 0, LS_ONEPASS = 1, LS_FLAGGED = 2, LS_DEDUPE = 3, LS_DEDUPE_ALL = 4 };
+constexpr uint32_t LS_FLAG = 0x80000000u;
+constexpr uint32_t LS_DONE = 0x40000000u;         // finished by the few-distinct-values plan: the general plan skips the task
+// LS_DEDUPE / LS_DEDUPE_ALL (round 3): the plan for tasks with FEW DISTINCT values (BASELINE configs[3]: after two partition levels a
+// Zipf task holds ~8 K keys of ~256 values in a 16-bit space -- too many per bin for the one-pass byte counters, and two passes in
+// the general plan).  A 2^B-bit map of the values present -> the rank of every present value among them (prefix popcount) -> one
+// counter per DISTINCT value -> one order-free pass, whatever B <= 16 is.  LS_DEDUPE takes flagged tasks (after LS_ONEPASS),
+// LS_DEDUPE_ALL any task (classes with no one-pass plan); both only look at tasks of more bits than the general plan's first pass
+// takes, only when the level showed skew, and only when a 64-key sample shows repeats; a task with more than DD_MAX distinct values is
+// left untouched for the general plan, a finished one gets LS_DONE.
+constexpr uint32_t DD_BITW = 4096;                // map words: {16 present-bits, 16-bit prefix}; 2^16 values at most
+constexpr uint32_t DD_MAX = 2048;                 // distinct values at most
+__host__ __device__ constexpr bool ls_is_dedupe(int mode) { return mode == LS_DEDUPE || mode == LS_DEDUPE_ALL; }
+constexpr uint32_t LS_DD = 0x20000000u;           // the task's sample shows repeats: a candidate for the few-distinct-values plan
+
+// A look at every task of a level that showed skew (some sub-bucket outgrew the local sorts and opened a next level), before
+// its local sorts: one wave per task reads 64 evenly spaced keys.  A value that shows up three times among them will overflow a
+// one-pass byte counter (it holds > 255 of <= 17408 keys): the task gets LS_FLAG, and the one-pass kernel leaves it alone without
+// the wasted attempt (Zipf 2^30: 10 000 such tasks cost 0.29 ms of failed attempts).  Four samples with a twin: LS_DD (256 distinct
+// values: ~14 of 64 samples have one; 2048: ~2).  Inside the sort kernels the same look was a dependent memory round trip per task
+// on the critical path (4000 clocks of a 41 000-clock task, tools/ls_phases.py); here all tasks are looked at at once.
+__global__ __launch_bounds__(256) void msb_task_sample_kernel(MsbWs ws, int L, const uint32_t *__restrict__ src_k, int has_values)
+{
+    if (!(L < 3 && (ws.level[L + 1].packed >> 32) != 0ull)) return;
+    const uint32_t lane = lane_id(), wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = (gridDim.x * blockDim.x) >> 6;
+    bool flagged = false;
+    for (int cls = 0; cls < MSB_NCLASS; ++cls) {
+        uint32_t ntasks = ws.level[L].task_count[cls];
+        if (ntasks > ws.max_tasks) ntasks = ws.max_tasks;
+        const int b1 = local_b1((int)ws.caps[cls]), onepass_bits = local_b1((int)ws.caps[cls] * (has_values ? 2 : 1)) + 2;
+        for (uint32_t t = wv; t < ntasks; t += nwv) {
+            const MsbTask c = ws.tasks[cls][t];
+            if (c.sort_bits <= (uint32_t)b1 || c.sort_bits > 16u || c.size < 64u) continue;
+            const uint32_t smp = src_k[c.offset + (uint32_t)(((unsigned long long)c.size * (2u * lane + 1u)) >> 7)];
+            unsigned long long same = ~0ull;
+            for (uint32_t b = 0; b < c.sort_bits; ++b) {
+                const bool bit = (smp >> b) & 1u;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(bit);
+                same &= bit ? m : ~m;
+            }
+            const int mult = __popcll(same);
+            uint32_t add = 0;
+            if (c.sort_bits <= (uint32_t)onepass_bits && __builtin_amdgcn_ballot_w64(mult >= 3) != 0ull) { add |= LS_FLAG; flagged = true; }
+            if (__popcll(__builtin_amdgcn_ballot_w64(mult >= 2)) >= 4) add |= LS_DD;
+            if (add && lane == 0) ws.tasks[cls][t].pad = c.pad | add;
+        }
+    }
+    if (flagged && lane == 0) ws.level[L].flagged = 1u;
+}
 #ifdef GS_EXP_LS_PHASES
 // experiment builds only (tools/ls_phases.py): shader-clock length of every phase of wave 0, per task; [plan][class][task][16]
 constexpr uint32_t LSP_TASKS = 65536;
-__device__ uint32_t gs_ls_phase_buf[2 * MSB_NCLASS * LSP_TASKS * 16];
+__device__ uint32_t gs_ls_phase_buf[3 * MSB_NCLASS * LSP_TASKS * 16];
+#define LSP_PLAN (MODE == LS_ONEPASS ? 0 : ls_is_dedupe(MODE) ? 2 : 1)
 #define LSP(k)                                                                                                         \
     do {                                                                                                               \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                  \
-        if (tid == 0 && ti < LSP_TASKS) gs_ls_phase_buf[(((MODE == LS_ONEPASS ? 0 : 1) * MSB_NCLASS + cls) * LSP_TASKS + ti) * 16 + (k)] += (uint32_t)(now_ - tprev_); \
+        if (tid == 0 && ti < LSP_TASKS) gs_ls_phase_buf[((LSP_PLAN * MSB_NCLASS + cls) * LSP_TASKS + ti) * 16 + (k)] += (uint32_t)(now_ - tprev_); \
         tprev_ = now_;                                                                                                 \
     } while (0)
 #define LSP_WAIT(what) asm volatile("s_waitcnt " what ::: "memory")
@@ -1032,7 +1081,6 @@ __device__ uint32_t gs_ls_phase_buf[2 * MSB_NCLASS * LSP_TASKS * 16];
 #define LSP(k) do { } while (0)
 #define LSP_WAIT(what) do { } while (0)
 #endif
-constexpr uint32_t LS_FLAG = 0x80000000u;
 // PLAIN: no key transform on the way in or out (u32 ascending): instantiated for the one-pass kernels, where it is 9 of ~30
 // vector instructions per key.
 template <int THREADS, int KPT, bool HAS_VALUES, bool STABLE = false, int MODE = LS_ALL, bool PLAIN = false>
@@ -1051,7 +1099,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
     __shared__ __attribute__((aligned(16))) LocalSmem<THREADS, KPT, HAS_VALUES> sm;
     uint32_t ntasks = ws.level[L].task_count[cls];
     if (ntasks > ws.max_tasks) ntasks = ws.max_tasks;
-    if (MODE == LS_FLAGGED && ws.level[L].flagged == 0u) return;     // nothing was left over (the usual case)
+    if ((MODE == LS_FLAGGED || MODE == LS_DEDUPE) && ws.level[L].flagged == 0u) return;     // nothing was left over (the usual case)
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     uint32_t *my = sm.whist[w];
     const uint32_t wbase0 = (uint32_t)w * (WAVE * KPT) + lane;
@@ -1059,31 +1107,17 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
     // KPT derived indices and addresses live across the task loop and spills them (64-VGPR budget)
     auto fresh = [](uint32_t x) { asm volatile("" : "+v"(x)); return x; };
     static_assert(!(STABLE && MODE != LS_ALL), "the stable sort has one plan");
-    // sampling costs a dependent memory round trip per task (uniform 2^30 keys: +0.26 ms over 65536 tasks), so it is
-    // done only where the level showed skew: some sub-bucket outgrew the local sorts and opened a next level
-    const bool look = MODE == LS_ONEPASS && L < 3 && (ws.level[L + 1].packed >> 32) != 0ull;
     // next task of this workgroup (stride gridDim.x) that this MODE processes; LS_ONEPASS flags the ones it leaves
     auto advance = [&](uint32_t from, MsbTask &out) {
         uint32_t t = from;
         for (; t < ntasks; t += gridDim.x) {
             const MsbTask c = ws.tasks[cls][t];
-            bool mine = MODE == LS_ALL ? true
-                        : MODE == LS_ONEPASS ? (c.sort_bits > (uint32_t)LOCAL_B1 && c.sort_bits <= (uint32_t)ONEPASS_BITS)
-                                             : (c.pad & LS_FLAG) != 0u;
-            if (MODE == LS_ONEPASS && mine && look) {
-                // a look before the attempt: 64 evenly spaced keys of the task; a value that shows up three times among
-                // them will overflow a byte counter (it holds > 255 of <= 17408 keys), so the task goes to the general
-                // plan without the wasted read (Zipf 2^30: 10 000 such tasks cost 0.29 ms of failed attempts); every
-                // wave takes the same samples, so the verdict is uniform in the workgroup
-                const uint32_t smp = src_k[c.offset + (uint32_t)(((unsigned long long)c.size * (2u * (uint32_t)lane + 1u)) >> 7)];
-                unsigned long long same = ~0ull;
-                for (uint32_t b = 0; b < c.sort_bits; ++b) {
-                    const bool bit = (smp >> b) & 1u;
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64(bit);
-                    same &= bit ? m : ~m;
-                }
-                if (__builtin_amdgcn_ballot_w64(__popcll(same) >= 3) != 0ull) mine = false;
-            }
+            // (the samples were looked at by msb_task_sample_kernel: LS_FLAG = a value heavy enough to overflow the one-pass
+            // counters, LS_DD = repeats enough for the few-distinct-values plan)
+            const bool mine = MODE == LS_ALL ? (STABLE || (c.pad & LS_DONE) == 0u)
+                        : MODE == LS_ONEPASS ? (c.sort_bits > (uint32_t)LOCAL_B1 && c.sort_bits <= (uint32_t)ONEPASS_BITS && (c.pad & LS_FLAG) == 0u)
+                        : MODE == LS_FLAGGED ? (c.pad & (LS_FLAG | LS_DONE)) == LS_FLAG
+                        : ((c.pad & LS_DD) != 0u && (MODE == LS_DEDUPE_ALL || (c.pad & LS_FLAG) != 0u) && c.sort_bits > (uint32_t)LOCAL_B1 && c.sort_bits <= 16u);
             if (mine) {   // wave-uniform: keep the record in scalar registers (the 64-VGPR budget of the big classes is tight)
                 out.offset = __builtin_amdgcn_readfirstlane(c.offset);
                 out.size = __builtin_amdgcn_readfirstlane(c.size);
@@ -1091,7 +1125,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                 out.pad = __builtin_amdgcn_readfirstlane(c.pad);
                 break;
             }
-            if (MODE == LS_ONEPASS && tid == 0) { ws.tasks[cls][t].pad = c.pad | LS_FLAG; ws.level[L].flagged = 1u; }
+            if (MODE == LS_ONEPASS && tid == 0 && (c.pad & LS_FLAG) == 0u) { ws.tasks[cls][t].pad = c.pad | LS_FLAG; ws.level[L].flagged = 1u; }
         }
         return t;
     };
@@ -1296,8 +1330,121 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                 }
             }
         }
+        if constexpr (ls_is_dedupe(MODE)) {
+            static_assert((uint32_t)(KPT * THREADS * (HAS_VALUES ? 2 : 1)) >= DD_BITW + DD_MAX, "the map and the counters are overlaid on the staging buffer");
+            static_assert(DD_BITW % THREADS == 0 && DD_MAX % THREADS == 0 && KPT * THREADS <= 65536, "dedupe geometry");
+            const uint32_t maskB = (1u << B) - 1u;
+            uint32_t *const bitw = sm.stage, *const cnt = sm.stage + DD_BITW;
+            for (uint32_t j = tid; j < DD_BITW + DD_MAX; j += THREADS) sm.stage[j] = 0;
+            __syncthreads();
+            LSP(2);                                       // zero the map and the counters + barrier
+            {   // mark the values present (a plain read first: after the first rounds almost every bit is set already).  One key
+                // after the other: batching the reads and the ORs of a thread (and the fetch-adds below) was measured slower --
+                // the waves then arrive at the barriers further apart (tools/ls_phases.py: 0.8 K -> 15 K clocks of barrier wait)
+                const uint32_t wbase = fresh(wbase0);
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    if (wbase + i * WAVE < T.size) {
+                        const uint32_t v = key[i] & maskB, bit = 1u << (v & 15u);
+                        if (!(bitw[v >> 4] & bit)) atomicOr(&bitw[v >> 4], bit);
+                    }
+                }
+            }
+            LSP_WAIT("lgkmcnt(0)");
+            LSP(3);                                       // mark
+            __syncthreads();
+            LSP(4);                                       // barrier
+            // ranks of the present values: exclusive prefix popcount over the map, kept in the upper half of every word
+            constexpr uint32_t WPT = DD_BITW / THREADS;
+            static_assert(WPT % 4 == 0, "map words per thread");
+            uint32_t ssum = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < WPT; q += 4) {
+                const uint4 c4 = reinterpret_cast<const uint4 *>(bitw)[((uint32_t)tid * WPT + q) >> 2];
+                ssum += (uint32_t)(__popc(c4.x) + __popc(c4.y) + __popc(c4.z) + __popc(c4.w));
+            }
+            uint32_t inc = wave_inclusive_scan(ssum);
+            if (lane == 63) sm.wtot[w] = inc;
+            __syncthreads();
+            uint32_t wsv = (lane < WAVES) ? sm.wtot[lane] : 0u;
+            uint32_t wincl = wave_inclusive_scan(wsv);
+            uint32_t run = (uint32_t)__shfl((int)(wincl - wsv), w, WAVE) + inc - ssum;
+            const uint32_t distinct = (uint32_t)__shfl((int)wincl, WAVES - 1, WAVE);
+            LSP(5);                                       // map scan (one barrier inside)
+            if (distinct <= DD_MAX) {                     // the same for every thread
+#pragma unroll
+                for (uint32_t q = 0; q < WPT; q += 4) {
+                    uint4 *p4 = reinterpret_cast<uint4 *>(bitw) + (((uint32_t)tid * WPT + q) >> 2);
+                    uint4 c4 = *p4;
+                    const uint32_t px = run, py = px + (uint32_t)__popc(c4.x), pz = py + (uint32_t)__popc(c4.y), pw = pz + (uint32_t)__popc(c4.z);
+                    run = pw + (uint32_t)__popc(c4.w);
+                    c4.x |= px << 16; c4.y |= py << 16; c4.z |= pz << 16; c4.w |= pw << 16;
+                    *p4 = c4;
+                }
+                __syncthreads();
+                LSP(6);                                   // prefixes written + barrier
+                {   // one counter per distinct value: the old count is the key's rank among its equals (order-free)
+                    const uint32_t wbase = fresh(wbase0);
+#pragma unroll
+                    for (int i = 0; i < KPT; ++i) {
+                        pos[i] = 0;
+                        if (wbase + i * WAVE < T.size) {
+                            const uint32_t v = key[i] & maskB, wd = bitw[v >> 4];
+                            const uint32_t id = (wd >> 16) + (uint32_t)__popc(wd & ((1u << (v & 15u)) - 1u));
+                            pos[i] = atomicAdd(&cnt[id], 1u) | (id << 16);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]), "+v"(key[i]));
+                LSP_WAIT("lgkmcnt(0)");
+                LSP(7);                                   // count
+                __syncthreads();
+                LSP(8);                                   // barrier
+                // exclusive scan of the counters in place
+                constexpr uint32_t CPT = DD_MAX / THREADS;
+                uint32_t c[CPT], csum = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < CPT; ++q) { c[q] = cnt[(uint32_t)tid * CPT + q]; csum += c[q]; }
+                inc = wave_inclusive_scan(csum);
+                if (lane == 63) sm.wtot[w] = inc;
+                __syncthreads();
+                wsv = (lane < WAVES) ? sm.wtot[lane] : 0u;
+                wincl = wave_inclusive_scan(wsv);
+                run = (uint32_t)__shfl((int)(wincl - wsv), w, WAVE) + inc - csum;
+#pragma unroll
+                for (uint32_t q = 0; q < CPT; ++q) { cnt[(uint32_t)tid * CPT + q] = run; run += c[q]; }
+                __syncthreads();
+                LSP(9);                                   // counter scan (two barriers)
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) pos[i] = cnt[pos[i] >> 16] + (pos[i] & 0xffffu);
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) asm volatile("" : "+v"(pos[i]));
+                LSP(10);                                  // base lookup
+                __syncthreads();                          // map and counters are dead: the buffer takes the keys
+                {
+                    const uint32_t wbase = fresh(wbase0);
+#pragma unroll
+                    for (int i = 0; i < KPT; ++i) {
+                        const uint32_t idx = wbase + i * WAVE;
+                        const uint32_t at = idx < T.size ? pos[i] : idx;      // a pad goes to its own load slot, behind the real keys
+                        if (HAS_VALUES) reinterpret_cast<uint2 *>(sm.stage)[at] = make_uint2(key[i], val[i]);
+                        else sm.stage[at] = key[i];
+                    }
+                }
+                LSP_WAIT("lgkmcnt(0)");
+                LSP(11);                                  // barrier + keys into the staging buffer
+                __syncthreads();
+                LSP(12);                                  // barrier
+                done = true;
+            } else {
+                __syncthreads();                          // everyone has read wtot before the next task reuses it
+            }
+        }
         if constexpr (MODE == LS_ONEPASS) {
             if (!done && tid == 0) { ws.tasks[cls][ti].pad = T.pad | LS_FLAG; ws.level[L].flagged = 1u; }   // a bin overflowed
+        } else if constexpr (ls_is_dedupe(MODE)) {
+            if (done && tid == 0) ws.tasks[cls][ti].pad = T.pad | LS_DONE;
         } else {
         done = true;
         const uint32_t b1 = STABLE ? 0u : (B < (uint32_t)LOCAL_B1 ? B : (uint32_t)LOCAL_B1);
@@ -1514,7 +1661,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
         __syncthreads();
 #ifdef GS_EXP_LS_PHASES
         if (tid == 0 && ti < LSP_TASKS) {                  // [15]: the task's whole time in shader clocks, barrier included
-            gs_ls_phase_buf[(((MODE == LS_ONEPASS ? 0 : 1) * MSB_NCLASS + cls) * LSP_TASKS + ti) * 16 + 15] += (uint32_t)(__builtin_amdgcn_s_memtime() - t0_);
+            gs_ls_phase_buf[((LSP_PLAN * MSB_NCLASS + cls) * LSP_TASKS + ti) * 16 + 15] += (uint32_t)(__builtin_amdgcn_s_memtime() - t0_);
             (void)r0_;
         }
 #endif
@@ -1579,7 +1726,7 @@ static inline bool onepass_possible(int min_bits, int b1, int onepass_bits)
 template <bool HAS_VALUES, bool STABLE = false>
 static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uint32_t *sk, uint32_t *dk, const uint32_t *sv,
                                uint32_t *dv, int f32_in, uint32_t xor_in, int f32_out, uint32_t xor_out, hipStream_t s,
-                               int min_bits = 0, uint64_t num_items = 0, const uint32_t *known_tasks = nullptr)
+                               int min_bits = 0, uint64_t num_items = 0, const uint32_t *known_tasks = nullptr, bool maybe_skew = true)
 {
     KernelTimer kt(GS_K_MSB_LOCAL_SORT, s);
     // grid-stride over the task list; few blocks suffice for the big classes (empty launches are not free)
@@ -1599,16 +1746,34 @@ static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uin
 #define GS_LS1P(C, HV, M, P) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV, STABLE, M, P>), dim3(grid_of(C)), \
                                                dim3(msb_class_threads(C)), 0, s, ws, L, C, sk, dk, sv, dv, f32_in, xor_in, f32_out, xor_out)
 #define GS_LS1(C, HV, M) GS_LS1P(C, HV, M, false)
+    // (a resident grid of 1024 workgroups striding over the list instead of one workgroup per task, up to 16384: Zipf local sorts 1.69 -> 1.84 ms)
+#define GS_LSDD(C, HV, M) hipLaunchKernelGGL((msb_local_sort_kernel<msb_class_threads(C), msb_class_kpt(C), HV, STABLE, M, false>),                \
+                                             dim3(grid_of(C)), dim3(msb_class_threads(C)), 0, s, ws, L, C, sk, dk, sv, dv,                             \
+                                             f32_in, xor_in, f32_out, xor_out)
     const bool plain = !f32_in && !xor_in && !f32_out && !xor_out;
+    // GS_MSB_DEDUPE=0 switches the few-distinct-values plan off (A/B measurements; read once per process)
+    static const bool dedupe_on = [] { const char *e = getenv("GS_MSB_DEDUPE"); return !(e && e[0] == '0'); }();
     // unstable sort: the one-pass kernel takes what it can and flags the rest for the general one
 #define GS_LS(C, HV)                                                                                                  \
     do {                                                                                                              \
+        constexpr bool DD = !STABLE && msb_class_cap(C) * (HV ? 2u : 1u) >= DD_BITW + DD_MAX;                           \
+        const bool dd = DD && dedupe_on && maybe_skew && L < 3 && onepass_possible(min_bits, local_b1((int)msb_class_cap(C)), 16);          \
         if constexpr (STABLE) { GS_LS1(C, HV, LS_ALL); }                                                              \
         else if (!onepass_possible(min_bits, local_b1((int)msb_class_cap(C)), local_b1((int)msb_class_cap(C) * (HV ? 2 : 1)) + 2)) \
-            { GS_LS1(C, HV, LS_ALL); }                                                                                \
-        else { if (plain) GS_LS1P(C, HV, LS_ONEPASS, true); else GS_LS1(C, HV, LS_ONEPASS); GS_LS1(C, HV, LS_FLAGGED); } \
+            { if constexpr (DD) { if (dd) GS_LSDD(C, HV, LS_DEDUPE_ALL); } GS_LS1(C, HV, LS_ALL); }                    \
+        else { if (plain) GS_LS1P(C, HV, LS_ONEPASS, true); else GS_LS1(C, HV, LS_ONEPASS);                           \
+               if constexpr (DD) { if (dd) GS_LSDD(C, HV, LS_DEDUPE); } GS_LS1(C, HV, LS_FLAGGED); }                   \
     } while (0)
     auto wanted = [&](int c) { return !known_tasks || known_tasks[c] != 0u; };
+    if constexpr (!STABLE) {
+        // the look at the tasks' samples (exits at once when the level showed no skew); one wave per task
+        uint64_t waves = bound;
+        if (known_tasks) waves = (uint64_t)known_tasks[0] + known_tasks[1] + known_tasks[2] + known_tasks[3];
+        if (L < 3 && waves && maybe_skew) {
+            const uint32_t blocks = (uint32_t)(waves / 4 + 1 < 2048 ? waves / 4 + 1 : 2048);
+            hipLaunchKernelGGL(msb_task_sample_kernel, dim3(blocks), dim3(256), 0, s, ws, L, sk, HAS_VALUES ? 1 : 0);
+        }
+    }
     if (wanted(0)) GS_LS(0, HAS_VALUES);
     if (wanted(1)) GS_LS(1, HAS_VALUES);
     if (wanted(2)) GS_LS(2, HAS_VALUES);
@@ -1616,6 +1781,7 @@ static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uin
 #undef GS_LS
 #undef GS_LS1
 #undef GS_LS1P
+#undef GS_LSDD
 }
 
 // Levels 1..3 (partition on bytes 2, 1, 0 + the local sorts after each): keys travel between
@@ -1791,8 +1957,9 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
             // a bucket emits at most 256 tasks
             const uint32_t tb = (uint64_t)max_b * RADIX < (uint64_t)max_tasks_lvl ? max_b * (uint32_t)RADIX : max_tasks_lvl;
             const uint32_t *kt_ = lk.ok ? lk.tasks : nullptr;
-            if (pairs) launch_local_sorts<true>(ws, L, tb, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L, num_items, kt_);
-            else launch_local_sorts<false>(ws, L, tb, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L, num_items, kt_);
+            const bool skew = !(lk.ok && lk.buckets == 0);   // the host has looked: no next level = nothing for the sample look to find
+            if (pairs) launch_local_sorts<true>(ws, L, tb, dk, d_keys, dv, d_vals, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L, num_items, kt_, skew);
+            else launch_local_sorts<false>(ws, L, tb, dk, d_keys, nullptr, nullptr, 0, 0u, tw.f32_out, tw.xor_out, s, 24 - 8 * L, num_items, kt_, skew);
             if (lk.ok) {
                 if (lk.buckets == 0) return;   // nothing left for the levels below
                 known = true; known_b = lk.buckets; known_tiles = lk.tiles;
@@ -2611,8 +2778,8 @@ int gs_exp_ls_phases(uint32_t *out)
 {
     void *p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(gs_ls_phase_buf)) != hipSuccess) return (int)hipGetLastError();
-    if (!out) return (int)hipMemset(p, 0, sizeof(uint32_t) * 2 * MSB_NCLASS * LSP_TASKS * 16);
-    return (int)hipMemcpy(out, p, sizeof(uint32_t) * 2 * MSB_NCLASS * LSP_TASKS * 16, hipMemcpyDeviceToHost);
+    if (!out) return (int)hipMemset(p, 0, sizeof(uint32_t) * 3 * MSB_NCLASS * LSP_TASKS * 16);
+    return (int)hipMemcpy(out, p, sizeof(uint32_t) * 3 * MSB_NCLASS * LSP_TASKS * 16, hipMemcpyDeviceToHost);
 }
 #endif
 #ifdef GS_EXP_CLS

@@ -313,3 +313,62 @@ def test_list_overflow_is_reported(gs, cuda, oracle, monkeypatch):
     dk = to_dev(keys, cuda)
     gs.rdxsrt_unstable_sort(dk, None, n, alt, None, pre_allocated_dm=dm)
     assert msb_census(dm, n)[0]["overflow"] == 0 and oracle.msb_check_keys(keys, to_u32(dk)[:n]) == 0
+
+
+def _few_distinct_case(rng, sizes, distincts, big=150_000):
+    """Keys whose level-1 sub-buckets (two top bytes fixed) hold sizes[i] keys of distincts[i] distinct 16-bit tails, plus one
+    sub-bucket too large for a local sort (so that the level shows skew and the samples are looked at)."""
+    parts = []
+    for j, (m, d) in enumerate(zip(sizes, distincts)):
+        prefix = ((0x10 + (j & 1) * 0x31) << 24) | ((j >> 1) << 16)
+        tails = rng.choice(65536, size=min(d, 65536), replace=False).astype(np.uint32)
+        idx = np.minimum((rng.random(m) ** 2 * len(tails)).astype(np.int64), len(tails) - 1)     # skewed multiplicities
+        idx[: len(tails)] = np.arange(len(tails))                                              # every tail at least once
+        parts.append(np.uint32(prefix) | tails[idx[:m]] if m >= len(tails) else np.uint32(prefix) | tails[:m])
+    parts.append(np.uint32(0x7f << 24 | 0x33 << 16) | rng.integers(0, 65536, big, dtype=np.uint32))
+    keys = np.concatenate(parts)
+    rng.shuffle(keys)
+    return keys
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+def test_few_distinct_values_plan(gs, cuda, oracle, pairs):
+    """The local sorts' plan for tasks with few distinct values (LS_DEDUPE / LS_DEDUPE_ALL, gs_msb.hip): 16-bit tasks of the two large
+    classes with 1 ... 2047, 2048, 2049 ... all-distinct values -- around DD_MAX = 2048 the plan must hand the task back untouched."""
+    rng = np.random.default_rng(77)
+    distincts = [1, 2, 3, 17, 100, 256, 257, 1000, 2047, 2048, 2049, 2100, 3000, 4700, 9000, 16, 255, 2048, 2047, 2049]
+    sizes = [9000, 9216, 4700, 8000, 9100, 9216, 7000, 9000, 9216, 9216, 9216, 9000, 9000, 9216, 9216,     # the 9216 class
+             17408, 17000, 17408, 12000, 17408]                                                              # the 17408 class
+    keys = _few_distinct_case(rng, sizes, distincts)
+    if not pairs:
+        got = _msb_keys(gs, keys, cuda)
+        assert oracle.msb_check_keys(keys, got) == 0
+    else:
+        vals = oracle.gen_uniform(keys.size, seed=5)
+        ks, vs = _msb_pairs(gs, keys, vals, cuda)
+        assert oracle.msb_check_pairs(keys, vals, ks, vs) == 0
+        vals = oracle.gen_enumerated(keys.size)
+        ks, vs = _msb_pairs(gs, keys, vals, cuda)
+        assert oracle.msb_check_pairs_enumerated(keys, ks, vs) == 0
+
+
+def test_few_distinct_values_plan_is_taken(gs, cuda, oracle, monkeypatch):
+    """The same input with the plan switched off (GS_MSB_DEDUPE=0, read once per process: a child process) sorts to the same keys."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import gpu_sort_amd as gs
+        from test_msb_gpu import _few_distinct_case
+        rng = np.random.default_rng(3)
+        keys = _few_distinct_case(rng, [9216] * 40 + [17408] * 20, [int(x) for x in rng.integers(1, 2300, 60)])
+        d = torch.from_numpy(keys.view(np.int32)).cuda(); alt = torch.empty_like(d)
+        gs.rdxsrt_unstable_sort(d, None, keys.size, alt, None)
+        got = d.cpu().numpy().view(np.uint32)
+        assert (got == np.sort(keys)).all()
+        print("ok")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    for flag in ("0", "1"):
+        env = dict(os.environ, GS_MSB_DEDUPE=flag)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

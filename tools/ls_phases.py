@@ -26,17 +26,20 @@ for r in range(3):
         torch.cuda.synchronize()
 print({k: round(v[0], 3) for k, v in prof.read().items()})
 NT, NC = 65536, 4
-out = np.zeros(2 * NC * NT * 16, dtype=np.uint32)
+out = np.zeros(3 * NC * NT * 16, dtype=np.uint32)
 assert raw.gs_exp_ls_phases(out.ctypes.data_as(C.c_void_p)) == 0
-m = out.reshape(2, NC, NT, 16).astype(np.float64)
+m = out.reshape(3, NC, NT, 16).astype(np.float64)
 names = {0: ["next task record", "wait for keys", "zero counters (1st task)", "count: fetch-adds", "barrier", "word sums + wave scan", "barrier",
              "bases over words", "barrier", "lookup", "barrier", "keys -> buffer", "barrier", "request next keys", "read buffer + stores", "TOTAL"],
          1: ["next task record", "wait for keys", "zero histogram + barrier", "1st pass fetch-adds", "barrier", "scan bins", "barrier",
-             "base lookup", "barrier", "keys -> buffer", "barrier", "stable passes", "-", "request next keys", "read buffer + stores", "TOTAL"]}
+             "base lookup", "barrier", "keys -> buffer", "barrier", "stable passes", "-", "request next keys", "read buffer + stores", "TOTAL"],
+         2: ["next task record", "wait for keys", "zero map + counters + barrier", "mark present values", "barrier", "map scan (1 barrier)",
+             "prefixes written + barrier", "count per distinct value", "barrier", "counter scan (2 barriers)", "base lookup", "barrier + keys -> buffer",
+             "barrier", "request next keys", "read buffer + stores", "TOTAL"]}
 from gpu_sort_amd.msb import msb_census
 cens = msb_census(dm, n, pairs)
 print("census tasks per level:", [c["tasks"] for c in cens], "task keys:", [c["task_keys"] for c in cens])
-for plan in (0, 1):
+for plan in (0, 1, 2):
     for cls in range(NC):
         t = m[plan, cls]
         live = t[:, 15] > 0
@@ -44,7 +47,7 @@ for plan in (0, 1):
         k = int(live.sum())
         tot = t[live, 15]
         print("\nplan %s class %d: %d tasks stamped (first %d of the list), mean %.0f clocks per task (p10 %.0f p90 %.0f)" %
-              ("one-pass" if plan == 0 else "general", cls, k, NT, tot.mean(), np.percentile(tot, 10), np.percentile(tot, 90)))
+              (("one-pass", "general", "few distinct values")[plan], cls, k, NT, tot.mean(), np.percentile(tot, 10), np.percentile(tot, 90)))
         for i in range(15):
             v = t[live, i].mean()
             if v > 0: print("   %-28s %8.0f clocks  %5.1f %%" % (names[plan][i], v, 100 * v / tot.mean()))
