@@ -1028,6 +1028,12 @@ constexpr uint32_t LS_DONE = 0x40000000u;         // finished by the few-distinc
 // left untouched for the general plan, a finished one gets LS_DONE.
 constexpr uint32_t DD_BITW = 4096;                // map words: {16 present-bits, 16-bit prefix}; 2^16 values at most
 constexpr uint32_t DD_MAX = 2048;                 // distinct values at most
+// Counters: DD_CNT words shared out as R = 2 ... 16 REPLICAS per distinct value (R = the largest power of two with distinct * R <= DD_CNT),
+// lane l adds to replica l % R.  Fetch-adds of one wave instruction on the SAME counter are served one after the other, and a Zipf task's
+// heaviest value sits in 5 of 64 lanes on average: with one counter per value the count phase was a quarter of the task (0.36 ms of
+// 1.72 ms at 2^30 Zipf keys went away in a timing experiment with artificially spread counters).  The replicas of a value are neighbours
+// in the array, so the exclusive scan over the array still yields every (value, replica)'s first output slot.
+constexpr uint32_t DD_CNT = 4096;
 __host__ __device__ constexpr bool ls_is_dedupe(int mode) { return mode == LS_DEDUPE || mode == LS_DEDUPE_ALL; }
 constexpr uint32_t LS_DD = 0x20000000u;           // the task's sample shows repeats: a candidate for the few-distinct-values plan
 
@@ -1331,12 +1337,16 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
             }
         }
         if constexpr (ls_is_dedupe(MODE)) {
-            static_assert((uint32_t)(KPT * THREADS * (HAS_VALUES ? 2 : 1)) >= DD_BITW + DD_MAX, "the map and the counters are overlaid on the staging buffer");
-            static_assert(DD_BITW % THREADS == 0 && DD_MAX % THREADS == 0 && KPT * THREADS <= 65536, "dedupe geometry");
+            static_assert((uint32_t)(KPT * THREADS * (HAS_VALUES ? 2 : 1)) >= DD_BITW + DD_CNT, "the map and the counters are overlaid on the staging buffer");
+            static_assert(DD_BITW % THREADS == 0 && DD_CNT % (4 * THREADS) == 0 && KPT * THREADS <= 65536 && DD_MAX * 2 <= DD_CNT, "dedupe geometry");
             const uint32_t maskB = (1u << B) - 1u;
             uint32_t *const bitw = sm.stage, *const cnt = sm.stage + DD_BITW;
-            for (uint32_t j = tid; j < DD_BITW + DD_MAX; j += THREADS) sm.stage[j] = 0;
-            __syncthreads();
+            // (keys only: every task after the block's first finds the buffer zeroed by the store phase of the task before)
+            if (!zeroed) {
+                for (uint32_t j = tid; j < DD_BITW + DD_CNT; j += THREADS) sm.stage[j] = 0;
+                __syncthreads();
+            }
+            zeroed = false;
             LSP(2);                                       // zero the map and the counters + barrier
             {   // mark the values present (a plain read first: after the first rounds almost every bit is set already).  One key
                 // after the other: batching the reads and the ORs of a thread (and the fetch-adds below) was measured slower --
@@ -1383,15 +1393,22 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                 }
                 __syncthreads();
                 LSP(6);                                   // prefixes written + barrier
-                {   // one counter per distinct value: the old count is the key's rank among its equals (order-free)
+                // replicas per value (see DD_CNT): 16 up to 256 distinct values, 8 up to 512, 4 up to 1024, else 2
+                const uint32_t rs = distinct <= 256u ? 4u : distinct <= 512u ? 3u : distinct <= 1024u ? 2u : 1u;
+                const uint32_t rep = (uint32_t)lane & ((1u << rs) - 1u);
+                {   // the old count of (value, replica) is the key's rank among the keys that share both (order-free)
                     const uint32_t wbase = fresh(wbase0);
 #pragma unroll
                     for (int i = 0; i < KPT; ++i) {
                         pos[i] = 0;
                         if (wbase + i * WAVE < T.size) {
                             const uint32_t v = key[i] & maskB, wd = bitw[v >> 4];
-                            const uint32_t id = (wd >> 16) + (uint32_t)__popc(wd & ((1u << (v & 15u)) - 1u));
+                            const uint32_t id = (((wd >> 16) + (uint32_t)__popc(wd & ((1u << (v & 15u)) - 1u))) << rs) | rep;
+#ifdef GS_EXP_DD_NOCONTEND      /* timing experiment only (wrong results): what do same-address fetch-adds cost? */
+                            pos[i] = atomicAdd(&cnt[(id + (uint32_t)lane * 31u) & (DD_CNT - 1u)], 1u) | (id << 16);
+#else
                             pos[i] = atomicAdd(&cnt[id], 1u) | (id << 16);
+#endif
                         }
                     }
                 }
@@ -1402,10 +1419,13 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                 __syncthreads();
                 LSP(8);                                   // barrier
                 // exclusive scan of the counters in place
-                constexpr uint32_t CPT = DD_MAX / THREADS;
-                uint32_t c[CPT], csum = 0;
+                constexpr uint32_t CPT = DD_CNT / THREADS;
+                uint32_t csum = 0;
 #pragma unroll
-                for (uint32_t q = 0; q < CPT; ++q) { c[q] = cnt[(uint32_t)tid * CPT + q]; csum += c[q]; }
+                for (uint32_t q = 0; q < CPT; q += 4) {
+                    const uint4 c4 = reinterpret_cast<const uint4 *>(cnt)[((uint32_t)tid * CPT + q) >> 2];
+                    csum += c4.x + c4.y + c4.z + c4.w;
+                }
                 inc = wave_inclusive_scan(csum);
                 if (lane == 63) sm.wtot[w] = inc;
                 __syncthreads();
@@ -1413,7 +1433,14 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
                 wincl = wave_inclusive_scan(wsv);
                 run = (uint32_t)__shfl((int)(wincl - wsv), w, WAVE) + inc - csum;
 #pragma unroll
-                for (uint32_t q = 0; q < CPT; ++q) { cnt[(uint32_t)tid * CPT + q] = run; run += c[q]; }
+                for (uint32_t q = 0; q < CPT; q += 4) {
+                    uint4 *p4 = reinterpret_cast<uint4 *>(cnt) + (((uint32_t)tid * CPT + q) >> 2);
+                    const uint4 c4 = *p4;
+                    uint4 e4;
+                    e4.x = run; e4.y = e4.x + c4.x; e4.z = e4.y + c4.y; e4.w = e4.z + c4.z;
+                    run = e4.w + c4.w;
+                    *p4 = e4;
+                }
                 __syncthreads();
                 LSP(9);                                   // counter scan (two barriers)
 #pragma unroll
@@ -1644,8 +1671,8 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
             const uint32_t t0 = fresh((uint32_t)tid);
 #pragma unroll
             for (int i = 0; i < KPT; ++i) pos[i] = sm.stage[t0 + i * THREADS];   // `pos` is free: batch the reads
-            if constexpr (MODE == LS_ONEPASS && !HAS_VALUES) {
-                // the slots become the next task's byte counters: each thread clears what it has just read
+            if constexpr ((MODE == LS_ONEPASS || ls_is_dedupe(MODE)) && !HAS_VALUES) {
+                // the slots become the next task's byte counters (map and counters): each thread clears what it has just read
 #pragma unroll
                 for (int i = 0; i < KPT; ++i) sm.stage[t0 + i * THREADS] = 0;
                 zeroed = true;
@@ -1756,7 +1783,7 @@ static void launch_local_sorts(const MsbWs &ws, int L, uint32_t bound, const uin
     // unstable sort: the one-pass kernel takes what it can and flags the rest for the general one
 #define GS_LS(C, HV)                                                                                                  \
     do {                                                                                                              \
-        constexpr bool DD = !STABLE && msb_class_cap(C) * (HV ? 2u : 1u) >= DD_BITW + DD_MAX;                           \
+        constexpr bool DD = !STABLE && msb_class_cap(C) * (HV ? 2u : 1u) >= DD_BITW + DD_CNT;                           \
         const bool dd = DD && dedupe_on && maybe_skew && L < 3 && onepass_possible(min_bits, local_b1((int)msb_class_cap(C)), 16);          \
         if constexpr (STABLE) { GS_LS1(C, HV, LS_ALL); }                                                              \
         else if (!onepass_possible(min_bits, local_b1((int)msb_class_cap(C)), local_b1((int)msb_class_cap(C) * (HV ? 2 : 1)) + 2)) \
