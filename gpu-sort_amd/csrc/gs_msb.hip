@@ -896,6 +896,91 @@ __device__ __forceinline__ void msb_pivot_tile(uint32_t *__restrict__ scratch /*
     }
 }
 
+// The same for (key, value) pairs (round 3): the values of the candidate's keys have to move too, so nothing is written in place.
+// Strangers go to their final ranges in `other` with their values; a pair of the candidate goes to a slot of the bucket's middle
+// range that the tile reserves (a third reservation per tile, P->cur_eq; any order will do: the sort is unstable) -- in `result`
+// when that is not the buffer being read (level 1: result == other), else in `other`, from where msb_pivot_copyback_kernel moves
+// the middle range to `result` once the level's scatter has finished (level 2).
+template <bool FULL>
+__device__ __forceinline__ void msb_pivot_tile_pairs(uint32_t *__restrict__ scratch /* LDS, >= 3 * MSB_WAVES + 3 words */,
+                                                     MsbPivot *__restrict__ P, const MsbBucket &B, const uint32_t *__restrict__ src_k,
+                                                     const uint32_t *__restrict__ src_v, uint32_t *__restrict__ other_k,
+                                                     uint32_t *__restrict__ other_v, uint32_t *__restrict__ mid_k,
+                                                     uint32_t *__restrict__ mid_v, uint32_t lo, uint32_t valid, int f32_out, uint32_t xor_out)
+{
+    const int lane = lane_id(), w = wave_id();
+    const uint32_t wbase = (uint32_t)w * (WAVE * MSB_KPT) + lane;
+    uint32_t key[MSB_KPT], val[MSB_KPT];
+    const uint32_t *pk = src_k + lo, *pv = src_v + lo;
+#pragma unroll
+    for (int i = 0; i < MSB_KPT; ++i) {
+        const uint32_t idx = wbase + i * WAVE, at = FULL ? idx : (idx < valid ? idx : valid - 1u);
+        key[i] = pk[at]; val[i] = pv[at];
+    }
+    const uint32_t cand = P->cand, mid_lo = B.offset + P->less;
+    const uint32_t cand_out = twiddle_out(cand, f32_out, xor_out);
+    uint32_t wl = 0, wg = 0, we = 0;   // wave-uniform counts
+#pragma unroll
+    for (int i = 0; i < MSB_KPT; ++i) {
+        const bool in = FULL || wbase + i * WAVE < valid;
+        wl += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(in && key[i] < cand));
+        wg += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(in && key[i] > cand));
+        we += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(in && key[i] == cand));
+    }
+    if (lane == 0) { scratch[w] = wl; scratch[MSB_WAVES + w] = wg; scratch[2 * MSB_WAVES + w] = we; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tl = 0, tg = 0, te = 0;
+#pragma unroll
+        for (int j = 0; j < MSB_WAVES; ++j) {
+            const uint32_t a = scratch[j], b2 = scratch[MSB_WAVES + j], c = scratch[2 * MSB_WAVES + j];
+            scratch[j] = tl; scratch[MSB_WAVES + j] = tg; scratch[2 * MSB_WAVES + j] = te;
+            tl += a; tg += b2; te += c;
+        }
+        scratch[3 * MSB_WAVES] = tl ? atomicAdd(&P->cur_less, tl) : 0u;
+        scratch[3 * MSB_WAVES + 1] = tg ? atomicAdd(&P->cur_greater, tg) : 0u;
+        scratch[3 * MSB_WAVES + 2] = te ? atomicAdd(&P->pad1, te) : 0u;       // pad1: the cursor of the middle range
+    }
+    __syncthreads();
+    uint32_t nl = B.offset + scratch[3 * MSB_WAVES] + scratch[w];                               // next free slot, from the front
+    uint32_t ng = B.offset + B.size - 1u - scratch[3 * MSB_WAVES + 1] - scratch[MSB_WAVES + w]; // from the back
+    uint32_t ne = mid_lo + scratch[3 * MSB_WAVES + 2] + scratch[2 * MSB_WAVES + w];             // in the middle
+#pragma unroll
+    for (int i = 0; i < MSB_KPT; ++i) {
+        const bool in = FULL || wbase + i * WAVE < valid;
+        const uint32_t k = key[i];
+        const unsigned long long ml = __builtin_amdgcn_ballot_w64(in && k < cand), mg = __builtin_amdgcn_ballot_w64(in && k > cand),
+                                 me = __builtin_amdgcn_ballot_w64(in && k == cand);
+        if (in) {
+            if (k < cand) { const uint32_t at = nl + count_lower_mask(ml); other_k[at] = k; other_v[at] = val[i]; }
+            else if (k > cand) { const uint32_t at = ng - count_lower_mask(mg); other_k[at] = k; other_v[at] = val[i]; }
+            else { const uint32_t at = ne + count_lower_mask(me); if (mid_k) mid_k[at] = cand_out; mid_v[at] = val[i]; }
+        }
+        nl += (uint32_t)__popcll(ml);
+        ng -= (uint32_t)__popcll(mg);
+        ne += (uint32_t)__popcll(me);
+    }
+}
+
+// Level 2, pairs: the middle ranges of the heavy-hitter buckets lie in the level's destination buffer (values only); the result
+// buffer gets the key value and the values, every tile of such a bucket moving its own slice of the middle range.
+__global__ __launch_bounds__(MSB_THREADS) void msb_pivot_copyback_kernel(MsbWs ws, int L, const uint32_t *__restrict__ from_v,
+                                                                         uint32_t *__restrict__ result_k, uint32_t *__restrict__ result_v,
+                                                                         int f32_out, uint32_t xor_out)
+{
+    const unsigned long long packed = ws.level[L].packed;
+    if (blockIdx.x >= (uint32_t)packed) return;
+    const MsbTile T = ws.tiles[blockIdx.x];
+    const MsbPivot P = ws.pivots[T.bucket];
+    if (!P.flag) return;
+    const MsbBucket B = ws.buckets[L & 1][T.bucket];
+    const uint32_t mid_lo = B.offset + P.less, mid_hi = mid_lo + P.eq, cand_out = twiddle_out(P.cand, f32_out, xor_out);
+    for (uint32_t i = threadIdx.x; i < T.valid; i += MSB_THREADS) {
+        const uint32_t at = T.lo + i;
+        if (at >= mid_lo && at < mid_hi) { result_k[at] = cand_out; result_v[at] = from_v[at]; }
+    }
+}
+
 // FULL = true: one block per level tile, dispatched in order; ragged tiles are skipped.
 // FULL = false: one block per bucket, for its ragged last tile (if any).  Two kernels keep the
 // guarded path's registers out of the hot one (as in the LSB downsweep).
@@ -905,7 +990,7 @@ template <bool HAS_VALUES, bool REMAP, bool TWOUT, bool FULL, bool BIG, bool PIV
 __global__ __launch_bounds__(MSB_THREADS, HAS_VALUES ? 4 : 6) void msb_scatter_kernel(
     MsbWs ws, int L, const uint32_t *__restrict__ src_k, uint32_t *__restrict__ dst_k, const uint32_t *__restrict__ src_v,
     uint32_t *__restrict__ dst_v, DigitSel ds, int f32_out, uint32_t xor_out, int ragged_anywhere,
-    uint32_t *__restrict__ result_k = nullptr, int pivot_f32_out = 0, uint32_t pivot_xor_out = 0u)
+    uint32_t *__restrict__ result_k = nullptr, int pivot_f32_out = 0, uint32_t pivot_xor_out = 0u, uint32_t *__restrict__ result_v = nullptr)
 {
     __shared__ __attribute__((aligned(16))) ScatterSmem<HAS_VALUES, REMAP> sm;
     const unsigned long long packed = ws.level[L].packed;
@@ -928,11 +1013,17 @@ __global__ __launch_bounds__(MSB_THREADS, HAS_VALUES ? 4 : 6) void msb_scatter_k
     }
     const MsbTile T = ws.tiles[g];
     if (FULL ? T.valid != (uint32_t)MSB_TILE : T.valid == (uint32_t)MSB_TILE) return;
-    if (PIVOT && !HAS_VALUES && ws.pivots[T.bucket].flag) {
+    if (PIVOT && ws.pivots[T.bucket].flag) {
         const MsbBucket B = ws.buckets[L & 1][T.bucket];
         const bool in_place = result_k == src_k;
-        msb_pivot_tile<FULL>(sm.gbase, ws.pivots + T.bucket, B, src_k, dst_k, result_k, T.lo, T.valid, pivot_f32_out, pivot_xor_out,
-                             !in_place || pivot_f32_out != 0 || pivot_xor_out != 0u);
+        if constexpr (HAS_VALUES) {
+            // (not in place: the level's destination IS the result buffer, level 1)
+            msb_pivot_tile_pairs<FULL>(sm.gbase, ws.pivots + T.bucket, B, src_k, src_v, dst_k, dst_v, in_place ? (uint32_t *)nullptr : result_k,
+                                       in_place ? dst_v : result_v, T.lo, T.valid, pivot_f32_out, pivot_xor_out);
+        } else {
+            msb_pivot_tile<FULL>(sm.gbase, ws.pivots + T.bucket, B, src_k, dst_k, result_k, T.lo, T.valid, pivot_f32_out, pivot_xor_out,
+                                 !in_place || pivot_f32_out != 0 || pivot_xor_out != 0u);
+        }
         return;
     }
     if (REMAP) load_remap(ds, sm.tab);
@@ -945,23 +1036,30 @@ template <bool HAS_VALUES, bool REMAP, bool TWOUT>
 static void launch_scatter(const MsbWs &ws, int L, uint32_t tiles_ub, uint32_t buckets_ub, bool big, const uint32_t *sk, uint32_t *dk,
                            const uint32_t *sv, uint32_t *dv, const DigitSel &ds, int f32_out, uint32_t xor_out, hipStream_t s,
                            bool ragged_anywhere = false, uint32_t *pivot_result = nullptr, int pivot_f32_out = 0,
-                           uint32_t pivot_xor_out = 0u)
+                           uint32_t pivot_xor_out = 0u, uint32_t *pivot_result_v = nullptr)
 {
     const dim3 blk(MSB_THREADS);
     const dim3 rg(ragged_anywhere ? tiles_ub : buckets_ub);
     const int ra = ragged_anywhere ? 1 : 0;
-    if constexpr (!HAS_VALUES && !REMAP) {
-        if (pivot_result) {   // heavy-hitter buckets may exist at this level (keys only)
+    if constexpr (!REMAP) {
+        if (pivot_result) {   // heavy-hitter buckets may exist at this level
             if (big) {
-                hipLaunchKernelGGL((msb_scatter_kernel<false, false, TWOUT, true, true, true>), dim3(tiles_ub), blk, 0, s, ws, L, sk, dk, sv,
-                                   dv, ds, f32_out, xor_out, 0, pivot_result, pivot_f32_out, pivot_xor_out);
-                hipLaunchKernelGGL((msb_scatter_kernel<false, false, TWOUT, false, true, true>), rg, blk, 0, s, ws, L, sk, dk, sv, dv, ds,
-                                   f32_out, xor_out, ra, pivot_result, pivot_f32_out, pivot_xor_out);
+                hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, false, TWOUT, true, true, true>), dim3(tiles_ub), blk, 0, s, ws, L, sk, dk, sv,
+                                   dv, ds, f32_out, xor_out, 0, pivot_result, pivot_f32_out, pivot_xor_out, pivot_result_v);
+                hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, false, TWOUT, false, true, true>), rg, blk, 0, s, ws, L, sk, dk, sv, dv, ds,
+                                   f32_out, xor_out, ra, pivot_result, pivot_f32_out, pivot_xor_out, pivot_result_v);
             } else {
-                hipLaunchKernelGGL((msb_scatter_kernel<false, false, TWOUT, true, false, true>), dim3(tiles_ub), blk, 0, s, ws, L, sk, dk, sv,
-                                   dv, ds, f32_out, xor_out, 0, pivot_result, pivot_f32_out, pivot_xor_out);
-                hipLaunchKernelGGL((msb_scatter_kernel<false, false, TWOUT, false, false, true>), rg, blk, 0, s, ws, L, sk, dk, sv, dv, ds,
-                                   f32_out, xor_out, ra, pivot_result, pivot_f32_out, pivot_xor_out);
+                hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, false, TWOUT, true, false, true>), dim3(tiles_ub), blk, 0, s, ws, L, sk, dk, sv,
+                                   dv, ds, f32_out, xor_out, 0, pivot_result, pivot_f32_out, pivot_xor_out, pivot_result_v);
+                hipLaunchKernelGGL((msb_scatter_kernel<HAS_VALUES, false, TWOUT, false, false, true>), rg, blk, 0, s, ws, L, sk, dk, sv, dv, ds,
+                                   f32_out, xor_out, ra, pivot_result, pivot_f32_out, pivot_xor_out, pivot_result_v);
+            }
+            if constexpr (HAS_VALUES) {
+                // pairs whose bucket lies in the result buffer itself: the middle ranges went to the destination buffer (values);
+                // now that every tile has been read, they move to the result
+                if (pivot_result == sk)
+                    hipLaunchKernelGGL(msb_pivot_copyback_kernel, dim3(tiles_ub), blk, 0, s, ws, L, (const uint32_t *)dv, pivot_result,
+                                       pivot_result_v, pivot_f32_out, pivot_xor_out);
             }
             return;
         }
@@ -1940,7 +2038,7 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
         const bool in_pieces = npieces != 0 && L == 1;
         // heavy-hitter path: keys only, buckets in one piece, and not at the last byte (a level-2 bucket's strangers
         // already cover it)
-        const bool pivot = allow_pivot && msb_pivot_enabled() && !pairs && !in_pieces && L <= 2;
+        const bool pivot = allow_pivot && msb_pivot_enabled() && !in_pieces && L <= 2;
         // buckets at level L: <= 256 at level 1, else bounded by size; tiles: n/T + one ragged tile per bucket (piece)
         uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
         uint32_t max_tiles = tiles_all + (in_pieces ? npieces : max_b);
@@ -1976,7 +2074,7 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
           const uint32_t *svc = pairs ? (const uint32_t *)sv : (const uint32_t *)nullptr;
           uint32_t *dvc = pairs ? dv : (uint32_t *)nullptr;
 #define GS_SC(HV, TW) launch_scatter<HV, false, TW>(ws, L, max_tiles, max_b, big, (const uint32_t *)sk, dk, svc, dvc, dsel, tw.f32_out, tw.xor_out, s, in_pieces, \
-                                                  pivot ? d_keys : (uint32_t *)nullptr, tw.f32_out, tw.xor_out)
+                                                  pivot ? d_keys : (uint32_t *)nullptr, tw.f32_out, tw.xor_out, pivot && pairs ? d_vals : (uint32_t *)nullptr)
           if (pairs) { if (last) GS_SC(true, true); else GS_SC(true, false); }
           else { if (last) GS_SC(false, true); else GS_SC(false, false); }
 #undef GS_SC

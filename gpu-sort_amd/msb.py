@@ -98,7 +98,8 @@ def msb_algorithmic_bytes(census, key_count, has_values=False):
     part = sum(c["keys"] - c["pivot_keys"] for c in lv)
     return {"lsb_upsweep": kb * key_count, "lsb_downsweep": 2 * mv * key_count,
             "msb_histogram": kb * sum(c["keys"] for c in lv),
-            "msb_partition": 2 * mv * part + kb * sum(c["pivot_keys"] for c in lv),
+            # a heavy-hitter bucket is read once; keys only: strangers are the only writes; pairs: every pair is written once
+            "msb_partition": 2 * mv * part + (2 * mv if has_values else kb) * sum(c["pivot_keys"] for c in lv),
             "msb_local_sort": 2 * mv * sum(c["task_keys"] for c in census)}
 
 

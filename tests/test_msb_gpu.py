@@ -372,3 +372,36 @@ def test_few_distinct_values_plan_is_taken(gs, cuda, oracle, monkeypatch):
         env = dict(os.environ, GS_MSB_DEDUPE=flag)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("share", [0.55, 0.9, 0.999])
+@pytest.mark.parametrize("level", [1, 2])
+def test_heavy_hitter_path_pairs(gs, cuda, oracle, share, level):
+    """The heavy-hitter path for (key, value) pairs (round 3): the values of the dominant key move to the middle of its bucket -- at
+    level 1 straight into the result buffer, at level 2 through the level's destination buffer and msb_pivot_copyback_kernel.
+    level 2: two values with the same top byte share the keys, so no level-1 bucket is dominated but two level-2 buckets are."""
+    from gpu_sort_amd.msb import msb_census
+    n = (1 << 21) + 4321
+    rng = np.random.default_rng(int(share * 1000) + level)
+    noise = oracle.gen_uniform(n, seed=3)
+    hot = rng.random(n) < share
+    for kt, a, b, view in ((gs.GS_KEY_U32, np.uint32(0xC0FF1234), np.uint32(0xC0EE5678), np.uint32),
+                           (gs.GS_KEY_I32, np.int32(-123456789).view(np.uint32), np.int32(-123456789 + (5 << 16)).view(np.uint32), np.int32)):
+        second = rng.random(n) < 0.5
+        hotvals = np.where(second, b, a) if level == 2 else np.full(n, a, dtype=np.uint32)
+        raw = np.where(hot, hotvals, noise).astype(np.uint32)
+        for vals in (oracle.gen_uniform(n, seed=11), oracle.gen_enumerated(n)):
+            dk, dv = to_dev(raw, cuda), to_dev(vals, cuda)
+            ka, va = torch.empty(n, dtype=torch.int32, device=cuda), torch.empty(n, dtype=torch.int32, device=cuda)
+            dm = torch.empty(gs.lib.gs_msb_temp_bytes(n, 1), dtype=torch.uint8, device=cuda)
+            seq = gs.rdxsrt_unstable_sort(dk, dv, n, ka, va, pre_allocated_dm=dm, key_type=kt)
+            ks, vs = to_u32(seq.sorted_keys)[:n], to_u32(seq.sorted_values)[:n]
+            got = ks.view(view)
+            assert np.all(got[1:] >= got[:-1])
+            # the pairs are a permutation of the input pairs: same multiset of (key, value)
+            pin = np.sort(raw.astype(np.uint64) << np.uint64(32) | vals.astype(np.uint64))
+            pout = np.sort(ks.astype(np.uint64) << np.uint64(32) | vs.astype(np.uint64))
+            assert np.array_equal(pin, pout)
+            cen = msb_census(dm, n, True)
+            assert sum(c["pivot_keys"] for c in cen) >= int(share * n * 0.99)
+            assert cen[level]["pivot_keys"] >= int(share * n * 0.99)
