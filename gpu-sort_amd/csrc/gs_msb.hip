@@ -2574,17 +2574,27 @@ __global__ __launch_bounds__(MW_THREADS, 4) void mw_scatter_kernel(MsbWs ws, int
 }
 
 // local sort of one class: LSD passes of 8 bits over the task's low `sort_bits` bits, all stable (ballot match), keys
-// (and values) exchanged through LDS after every pass; pads are all-ones keys, which every pass ranks last
+// (and values) exchanged through LDS after every pass; pads are all-ones keys, which every pass ranks last.
+// `unstable_ok` (the MSB sort; round 3), 64-bit keys with more than 16 bits left: ONE order-free counting pass on the task's top 11
+// bits (2048 bins for <= 8192 keys: a handful of keys per bin on anything like uniform keys), then every thread finishes four
+// neighbouring bins by insertion on the full key -- two trips through LDS instead of six LSD passes for the 48 bits a level-1 task
+// of a 64-bit sort has left (2^28 uniform u64 keys: local sorts 5.5 -> see DESIGN.md).  With values the element's index rides in
+// the key's top 16 bits (which every key of a task shares: <= 48 bits to sort) and the values are fetched through it at the end.
+// A bin of MW_BIN_LIMIT or more keys (skew): the task falls back to the LSD passes.
+constexpr uint32_t MW_BINS = 2048, MW_BIN_BITS = 11, MW_BIN_LIMIT = 24;
 template <typename K, typename V, int KPT>
 __global__ __launch_bounds__(MW_THREADS, KPT > 8 ? 2 : 4) void mw_local_sort_kernel(MsbWs ws, int L, int cls, const K *__restrict__ src_k,
                                                                                     K *__restrict__ dst_k, const V *__restrict__ src_v,
-                                                                                    V *__restrict__ dst_v, int f, uint64_t x)
+                                                                                    V *__restrict__ dst_v, int f, uint64_t x, int unstable_ok = 0)
 {
     constexpr bool HAS_VALUES = !std::is_same<V, MwNoVal>::value;
     constexpr size_t ELEM = sizeof(K) > (HAS_VALUES ? sizeof(V) : 1) ? sizeof(K) : sizeof(V);
     constexpr int CAP = MW_THREADS * KPT;
     __shared__ __attribute__((aligned(16))) uint32_t whist[MW_WAVES][RADIX];
     __shared__ __attribute__((aligned(16))) unsigned char stage_raw[CAP * ELEM];
+    __shared__ uint32_t mw_wtot[MW_WAVES];
+    __shared__ K mw_prefix;
+    static_assert(MW_WAVES * RADIX == MW_BINS && MW_BINS == 4 * MW_THREADS, "the bins of the order-free pass live in the wave counters");
     K *stage_k = reinterpret_cast<K *>(stage_raw);
     V *stage_v = reinterpret_cast<V *>(stage_raw);
     uint32_t ntasks = ws.level[L].task_count[cls];
@@ -2598,12 +2608,124 @@ __global__ __launch_bounds__(MW_THREADS, KPT > 8 ? 2 : 4) void mw_local_sort_ker
         K key[KPT];
         V val[HAS_VALUES ? KPT : 1];
         uint32_t pos[KPT];
+        // the order-free plan (below) deals the elements out round-robin over the workgroup, so that a task smaller than the class
+        // keeps every wave busy (wave-contiguous: a 4096-key task of the 8192 class left four of the eight waves idle)
+        const bool fast = sizeof(K) == 8 && unstable_ok && T.pad == 0u && T.sort_bits > 16u && (!HAS_VALUES || T.sort_bits <= 48u);   // uniform
+        const uint32_t ibase = fast ? (uint32_t)threadIdx.x : wbase, istep = fast ? (uint32_t)MW_THREADS : (uint32_t)WAVE;
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            const uint32_t idx = wbase + i * WAVE;
+            const uint32_t idx = ibase + i * istep;
             const K k = mw_tw_in<K>(src_k[T.offset + (idx < size ? idx : last)], f, x);
             key[i] = idx < size ? k : (K) ~(K)0;
             if constexpr (HAS_VALUES) val[i] = src_v[T.offset + (idx < size ? idx : last)];
+        }
+        bool finished = false;
+        if constexpr (sizeof(K) == 8) {
+            if (fast) {
+                constexpr K LOW48 = (K)0x0000ffffffffffffull;
+                uint32_t *hist = &whist[0][0];
+                const int tid = (int)threadIdx.x;
+                const uint32_t bshift = T.sort_bits - MW_BIN_BITS;
+                reinterpret_cast<uint4 *>(hist)[tid] = make_uint4(0u, 0u, 0u, 0u);
+                if (tid == 0) mw_prefix = key[0];          // element 0 is never a pad
+                __syncthreads();
+                uint32_t over = 0;
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    pos[i] = 0;
+                    if (ibase + i * istep < size) {
+                        pos[i] = atomicAdd(&hist[(uint32_t)(key[i] >> bshift) & (MW_BINS - 1u)], 1u);
+                        over |= pos[i] >= MW_BIN_LIMIT - 1u ? 1u : 0u;
+                    }
+                }
+                if (!__syncthreads_or((int)over)) {
+                    // exclusive scan of the bins in place: four neighbouring bins per thread
+                    const uint4 c4 = reinterpret_cast<const uint4 *>(hist)[tid];
+                    const uint32_t sum = c4.x + c4.y + c4.z + c4.w, inc = wave_inclusive_scan(sum);
+                    if (lane == 63) mw_wtot[w] = inc;
+                    __syncthreads();
+                    uint32_t run = inc - sum;
+#pragma unroll
+                    for (int j = 0; j < MW_WAVES; ++j) run += j < w ? mw_wtot[j] : 0u;
+                    const uint32_t b0 = run, b1 = b0 + c4.x, b2 = b1 + c4.y, b3 = b2 + c4.z, b4 = b3 + c4.w;
+                    reinterpret_cast<uint4 *>(hist)[tid] = make_uint4(b0, b1, b2, b3);
+                    __syncthreads();
+                    // into the buffer, bin by bin; with values an element is {low 48 key bits : 48, its index : 16}, so elements are
+                    // distinct and their unsigned order is the order of the keys
+                    K elem[KPT];
+#pragma unroll
+                    for (int i = 0; i < KPT; ++i) {
+                        const uint32_t idx = ibase + i * istep;
+                        elem[i] = HAS_VALUES ? (K)(((key[i] & LOW48) << 16) | (K)idx) : key[i];
+                        if (idx < size) {
+                            pos[i] += hist[(uint32_t)(key[i] >> bshift) & (MW_BINS - 1u)];
+                            stage_k[pos[i]] = elem[i];
+                        }
+                    }
+                    __syncthreads();
+                    // rank inside the bin by counting: every key reads its bin (a handful of elements) -- a thread-per-bin insertion
+                    // sort was a chain of dependent LDS round trips (3.0 of the kernel's 4.6 ms at 2^28 uniform u64 keys; counting:
+                    // 2.1 of 3.7 ms, and 1.0 of 2.6 ms once the elements are dealt out round-robin); all keys of a thread advancing
+                    // in lockstep rounds instead of key by key: slower (4.2 against 3.75 ms).  Equal keys (no values) are
+                    // ordered by their slot
+                    uint32_t fin[KPT];
+#pragma unroll
+                    for (int i = 0; i < KPT; ++i) {
+                        fin[i] = 0;
+                        if (ibase + i * istep < size) {
+                            const K kk = HAS_VALUES ? (K)(elem[i] >> 16) : elem[i];
+                            const uint32_t bin = (uint32_t)(kk >> bshift) & (MW_BINS - 1u);
+                            const uint32_t lo = hist[bin], hi = bin == MW_BINS - 1u ? size : hist[bin + 1u];
+                            uint32_t c = lo;
+                            for (uint32_t q = lo; q < hi; ++q) {
+                                const K e = stage_k[q];
+                                c += (e < elem[i] || (!HAS_VALUES && e == elem[i] && q < pos[i])) ? 1u : 0u;
+                            }
+                            fin[i] = c;
+                        }
+                    }
+                    __syncthreads();                       // every bin has been read: the elements move to their final slots
+#pragma unroll
+                    for (int i = 0; i < KPT; ++i)
+                        if (ibase + i * istep < size) stage_k[fin[i]] = elem[i];
+                    __syncthreads();
+                    const K prefix = mw_prefix & ~LOW48;
+#pragma unroll
+                    for (int i = 0; i < KPT; ++i) {
+                        const uint32_t slot = ibase + i * istep;
+                        if (slot < size) {
+                            K k = stage_k[slot];
+                            if constexpr (HAS_VALUES) { pos[i] = (uint32_t)k & 0xffffu; k = (K)((k >> 16) | prefix); }
+                            dst_k[T.offset + slot] = mw_tw_out<K>(k, f, x);
+                        }
+                    }
+                    if constexpr (HAS_VALUES) {
+                        __syncthreads();                   // every key has been read: the buffer takes the values, by original index
+#pragma unroll
+                        for (int i = 0; i < KPT; ++i) stage_v[ibase + i * istep] = val[i];
+                        __syncthreads();
+#pragma unroll
+                        for (int i = 0; i < KPT; ++i) {
+                            const uint32_t slot = ibase + i * istep;
+                            if (slot < size) dst_v[T.offset + slot] = stage_v[pos[i]];
+                        }
+                    }
+                    finished = true;
+                }
+                __syncthreads();
+            }
+        }
+        if (finished) continue;
+        if (fast) {
+            // the attempt was abandoned (a crowded bin): the LSD passes need the wave-contiguous order -- a pad (all ones) and a real
+            // key whose sorted bits are all ones are told apart only by the pads coming LAST in the order the stable passes keep
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const uint32_t idx = wbase + i * WAVE;
+                const K k = mw_tw_in<K>(src_k[T.offset + (idx < size ? idx : last)], f, x);
+                key[i] = idx < size ? k : (K) ~(K)0;
+                if constexpr (HAS_VALUES) val[i] = src_v[T.offset + (idx < size ? idx : last)];
+            }
         }
         // the task's bits start at bit `pad` of the key (0 in the MSB sort, begin_bit in a segmented sort); the last digit
         // may be narrower than 8 bits.  Pads are all-ones keys: the widest digit value in every pass, so they rank last.
@@ -2652,12 +2774,15 @@ __global__ void mw_single_task_kernel(MsbWs ws, uint32_t n, int cls, uint32_t bi
 }
 
 template <typename K, typename V>
-static void mw_launch_local_sorts(const MsbWs &ws, int L, const K *sk, K *dk, const V *sv, V *dv, int f, uint64_t x, hipStream_t s)
+static void mw_launch_local_sorts(const MsbWs &ws, int L, const K *sk, K *dk, const V *sv, V *dv, int f, uint64_t x, hipStream_t s,
+                                  bool unstable_ok = false)
 {
     KernelTimer kt(GS_K_MSB_LOCAL_SORT, s);
     const uint32_t g = ws.max_tasks < MSB_MAX_GRID ? ws.max_tasks : MSB_MAX_GRID;
-    hipLaunchKernelGGL((mw_local_sort_kernel<K, V, 4>), dim3(g), dim3(MW_THREADS), 0, s, ws, L, 0, sk, dk, sv, dv, f, x);
-    hipLaunchKernelGGL((mw_local_sort_kernel<K, V, 16>), dim3(g), dim3(MW_THREADS), 0, s, ws, L, 1, sk, dk, sv, dv, f, x);
+    static const bool fast_on = [] { const char *e = getenv("GS_MSB_WIDE_FAST"); return !(e && e[0] == '0'); }();   // A/B switch
+    const int u = unstable_ok && fast_on ? 1 : 0;
+    hipLaunchKernelGGL((mw_local_sort_kernel<K, V, 4>), dim3(g), dim3(MW_THREADS), 0, s, ws, L, 0, sk, dk, sv, dv, f, x, u);
+    hipLaunchKernelGGL((mw_local_sort_kernel<K, V, 16>), dim3(g), dim3(MW_THREADS), 0, s, ws, L, 1, sk, dk, sv, dv, f, x, u);
 }
 
 static size_t mw_lsb_bytes(uint64_t n, int kb, int vb) { return align256(gs_lsb_wide_temp_bytes(n, kb, vb)); }
@@ -2676,7 +2801,7 @@ static int msb_wide_sort(void *d_temp, K *keys, V *vals, uint64_t num_items, K *
     { KernelTimer kt(GS_K_OTHER, s); hipLaunchKernelGGL(msb_init_kernel, dim3(1), dim3(64), 0, s, ws, n); }
     if (n <= MW_CAP) {
         hipLaunchKernelGGL(mw_single_task_kernel, dim3(1), dim3(64), 0, s, ws, n, n <= 2048u ? 0 : 1, (uint32_t)key_bits);
-        mw_launch_local_sorts<K, V>(ws, 0, keys, keys, vals, vals, f, x, s);
+        mw_launch_local_sorts<K, V>(ws, 0, keys, keys, vals, vals, f, x, s, true);
         return (int)hipGetLastError();
     }
     // level 0: the top byte with one stable wide LSB pass, IN -> ALT (keys keep the caller's representation)
@@ -2687,7 +2812,7 @@ static int msb_wide_sort(void *d_temp, K *keys, V *vals, uint64_t num_items, K *
     if (e) return e;
     { KernelTimer kt(GS_K_MSB_CLASSIFY, s);
       hipLaunchKernelGGL((msb_classify_kernel<false, false>), dim3(1), dim3(256), 0, s, ws, 0, wide_totals_ptr(d_temp, num_items), nclass); }
-    mw_launch_local_sorts<K, V>(ws, 0, keys_alt, keys, vals_alt, vals, f, x, s);
+    mw_launch_local_sorts<K, V>(ws, 0, keys_alt, keys, vals_alt, vals, f, x, s, true);
     K *buf_k[2] = {keys, keys_alt};
     V *buf_v[2] = {vals, vals_alt};
     const uint32_t tiles_all = (uint32_t)((num_items + MW_TILE - 1) / MW_TILE);
@@ -2736,7 +2861,7 @@ static int msb_wide_sort(void *d_temp, K *keys, V *vals, uint64_t num_items, K *
         }
         { KernelTimer kt(GS_K_MSB_PARTITION, s);
           hipLaunchKernelGGL((mw_scatter_kernel<K, V>), dim3(max_tiles), dim3(MW_THREADS), 0, s, ws, L, sk, dk, sv, dv, shift, f, x); }
-        if (!last) mw_launch_local_sorts<K, V>(ws, L, (const K *)dk, buf_k[0], (const V *)dv, buf_v[0], f, x, s);
+        if (!last) mw_launch_local_sorts<K, V>(ws, L, (const K *)dk, buf_k[0], (const V *)dv, buf_v[0], f, x, s, true);
     }
     return (int)hipGetLastError();
 }
