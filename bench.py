@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configurations reported under `also`")
     ap.add_argument("--also-steps", type=int, default=5)
+    ap.add_argument("--also-late-alloc", action="store_true", help="allocate the `also` arrays after the headline run instead of first (placement experiments)")
     ap.add_argument("--cpu-sample-log2", type=int, default=27)
     ap.add_argument("--verify", action="store_true", help="device-side sortedness + checksum on every step")
     ap.add_argument("--exchange-groups", type=int, default=0,
@@ -154,7 +155,7 @@ def box_facts(torch, dev):
     return out
 
 
-def also_configs(gs, torch, dev, n, steps, log2n):
+def also_configs(gs, torch, dev, n, steps, log2n, bufs=None):
     """BASELINE.json configs[2..4] next to the headline (N = 1): each workload sorted `steps` times from a restored
     input, every sort bracketed by an event pair on its stream (median reported), the last result checked on the
     device.  Returns {workload: {...}}."""
@@ -172,14 +173,12 @@ def also_configs(gs, torch, dev, n, steps, log2n):
         ms = sorted(x.elapsed_time(y) for x, y in evs[1:])
         return ms[len(ms) // 2], ms[0], res
 
-    src = torch.empty(n, dtype=torch.int32, device=dev)
-    work = torch.empty(n, dtype=torch.int32, device=dev)
-    alt = torch.empty(n, dtype=torch.int32, device=dev)
+    if bufs is None:
+        bufs = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(5)]
+    src, work, alt, vals, vals_alt = bufs
 
     # ---- configs[2]: LSB, (u32 key, u32 value) pairs
     gs.generate_uniform_keys(n, seed=101, device=dev, out=src)
-    vals = torch.empty(n, dtype=torch.int32, device=dev)
-    vals_alt = torch.empty(n, dtype=torch.int32, device=dev)
     nbytes = gs.lib.gs_lsb_temp_bytes(n, 1)
     temp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     state = {}
@@ -207,7 +206,7 @@ def also_configs(gs, torch, dev, n, steps, log2n):
         "roofline": {"kernel": "lsb_downsweep", "algorithmic_bytes": 16 * n, "avg_launch_ms": round(ds_ms, 4), "achieved": round(gbs, 1),
                      "frac": round(gbs / HBM_PEAK_GBS, 4)},
         "verified": bool(inv == 0 and bad == 0), "check": "sorted on the device + every value still points at its key (gs_check_pairs_enumerated_u32)"}
-    del vals, vals_alt, temp
+    del vals, vals_alt, temp, bufs
 
     # ---- MSB: configs[3] (Zipf keys) and uniform keys
     nbytes = gs.lib.gs_msb_temp_bytes(n, 0)
@@ -322,6 +321,12 @@ def main():
     total = steps + warmup
 
     gen = gs.generate_uniform_keys if args.dist == "uniform" else gs.generate_zipf_keys
+    # the five arrays of the `also` workloads are allocated FIRST, the way a long-lived caller holds its sort buffers from start-up
+    # on: what the pairs sort takes depends on where its arrays lie (profiles/README.md, round 3), and arrays allocated after the
+    # headline's 23 x 4 GiB of inputs have been freed landed on the slow side in every run (4.0-4.2 ms per downsweep against 3.3)
+    also_wanted = (world == 1 and not args.force_sharded and not args.one_rank_rccl and algo == "lsb" and not args.pairs
+                   and args.dist == "uniform" and not args.no_also and args.also_steps > 0)
+    also_bufs = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(5)] if also_wanted and not args.also_late_alloc else None
     # one input buffer per step (4 GiB each at 2^30): nothing but the sort runs in the timed region
     inputs = [gen(n, seed=i, start=rank * n, device=dev) for i in range(total)]
     alt = torch.empty(n, dtype=torch.int32, device=dev)
@@ -534,7 +539,7 @@ def main():
             checks.clear()
             del alt, temp
             torch.cuda.empty_cache()
-            also = also_configs(gs, torch, dev, n, args.also_steps, args.log2n)
+            also = also_configs(gs, torch, dev, n, args.also_steps, args.log2n, also_bufs)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(min(args.cpu_sample_log2, args.log2n), args.pairs)
