@@ -354,20 +354,24 @@ __global__ __launch_bounds__(MSB_THREADS) void msb_upsweep_kernel(MsbWs ws, int 
                 auto digit_of = [&](uint32_t raw) {
                     return __builtin_amdgcn_ubfe(ds.tw_in ? twiddle_in(raw, ds.f32_in, ds.xor_in) : raw, (uint32_t)ds.shift, wbits);
                 };
+#ifndef GS_MSB_UPS_LEAN_BATCH
+#define GS_MSB_UPS_LEAN_BATCH 32
+#endif
+                constexpr int LB = GS_MSB_UPS_LEAN_BATCH;      // the lean path's own batch (the other paths keep BATCH)
 #pragma unroll 1
-                for (int j = 0; j < MSB_TILE / WAVE; j += BATCH) {
-                    uint32_t v[BATCH];
+                for (int j = 0; j < MSB_TILE / WAVE; j += LB) {
+                    uint32_t v[LB];
 #pragma unroll
-                    for (int u = 0; u < BATCH; ++u) v[u] = __builtin_nontemporal_load(&p[(j + u) * WAVE + lane]);
-                    const uint32_t da = digit_of(v[0]), db = digit_of(v[BATCH / 2]);
+                    for (int u = 0; u < LB; ++u) v[u] = __builtin_nontemporal_load(&p[(j + u) * WAVE + lane]);
+                    const uint32_t da = digit_of(v[0]), db = digit_of(v[LB / 2]);
                     const bool hot = __builtin_amdgcn_ballot_w64(da == __builtin_amdgcn_readfirstlane(da)) == ~0ull ||
                                      __builtin_amdgcn_ballot_w64(db == __builtin_amdgcn_readfirstlane(db)) == ~0ull;
                     if (hot) {
 #pragma unroll
-                        for (int u = 0; u < BATCH; ++u) hist_add(my, digit_of(v[u]));
+                        for (int u = 0; u < LB; ++u) hist_add(my, digit_of(v[u]));
                     } else {
 #pragma unroll
-                        for (int u = 0; u < BATCH; ++u) atomicAdd(&my[digit_of(v[u])], 1u);
+                        for (int u = 0; u < LB; ++u) atomicAdd(&my[digit_of(v[u])], 1u);
                     }
                 }
             } else if (T.valid == (uint32_t)MSB_TILE) {
