@@ -55,6 +55,21 @@ def make_keys(n, kind):
         k = torch.sort(rnd())[0]
     elif kind == "reverse":
         k = torch.sort(rnd(), descending=True)[0]
+    elif kind == "zipf":
+        k = gs.generate_zipf_keys(n, seed=int(rng.integers(0, 1 << 30)), device=dev) if n else rnd()
+    elif kind == "clustered":
+        # buckets of two fixed top bytes holding a few thousand keys with few distinct 16-bit tails each (the MSB local sorts' plan
+        # for few distinct values), one of them far too large for a local sort (so that the level shows skew)
+        if n == 0:
+            return rnd()
+        P = max(1, n // int(rng.integers(3000, 16000)))
+        pref = torch.randint(0, 1 << 16, (P,), device=dev, generator=g)
+        which = torch.randint(0, P, (n,), device=dev, generator=g)
+        which[torch.rand(n, device=dev, generator=g) < 0.15] = 0
+        D = int(rng.choice([1, 2, 7, 100, 255, 256, 1000, 2047, 2048, 2049, 5000]))
+        tail = (torch.randint(0, D, (n,), device=dev, generator=g) * 40503 + which * 977) & 0xFFFF
+        k = ((pref[which] << 16) | tail).to(torch.int64)
+        k = torch.where(k >= 2**31, k - 2**32, k).to(torch.int32)
     elif kind == "low_bytes":
         k = rnd() & 0xFFFF
     else:   # hot top byte
@@ -300,7 +315,7 @@ def shard_case(it):
             fail("sharded finish values", **case)
 
 
-KINDS = ["uniform", "and1", "and3", "and6", "and10", "few", "const", "ones_heavy", "sorted", "reverse", "low_bytes", "hot"]
+KINDS = ["uniform", "and1", "and3", "and6", "and10", "few", "const", "ones_heavy", "sorted", "reverse", "low_bytes", "hot", "zipf", "clustered"]
 counts = {}
 for it in range(iters):
     algo = str(rng.choice(["lsb", "lsb", "msb", "msb", "seg", "wide", "any"]))
