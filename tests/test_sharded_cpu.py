@@ -124,7 +124,9 @@ def _worker(rank, world, port, n, dist_kind, pairs, out_dir, pipeline="msb", gro
                           (2, "uniform", True, "partition", 4, None), (4, "zipf", False, "partition", 4, None),
                           # messages capped at 1500 elements: every exchange goes out in several rounds
                           (2, "uniform", True, "msb", 4, 1500), (3, "uniform", False, "msb", 1, 1500),
-                          (2, "zipf", True, "partition", 4, 1500)])
+                          (2, "zipf", True, "partition", 4, 1500),
+                          # the rank count of BASELINE configs[4]
+                          (8, "uniform", False, "msb", 4, None), (8, "zipf", True, "msb", 2, 1500)])
 def test_sharded_sort_over_gloo(tmp_path, oracle, world, dist_kind, pairs, pipeline, groups, max_msg, n=50000):
     mp.spawn(_worker, args=(world, _free_port(), n, dist_kind, pairs, str(tmp_path), pipeline, groups, max_msg), nprocs=world,
              join=True)
