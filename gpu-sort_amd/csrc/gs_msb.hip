@@ -144,6 +144,23 @@ __host__ __device__ inline uint32_t ws_tiles_of(const MsbWs &ws, uint32_t x)
     return (x >> ws.tile_shift) + ((x & ((1u << ws.tile_shift) - 1u)) ? 1u : 0u);
 }
 
+// Tiles of a bucket (round 3): a bucket of MSB_ALIGN_MIN_TILES tiles or more (2 M keys: the level-1 buckets of a large sort) that does not start on a MSB_TILE_ALIGN-element boundary
+// gets a SHORTER first tile, so that all its other tiles start on one: a wave's 256-byte loads then cover two cache lines, not
+// three.  With every bucket's top byte holding exactly n/256 keys (all tiles aligned like the LSB sort's) the level-1 histogram of
+// 2^30 keys took 0.75 ms instead of 0.84 and the scatter 1.71 instead of 1.78 (tools/align_exp.py).  Small buckets keep one ragged
+// tile (their last): a second one would cost them more than the alignment gives.
+constexpr uint32_t MSB_TILE_ALIGN = 64, MSB_ALIGN_MIN_TILES = 256;
+__host__ __device__ inline uint32_t ws_first_tile(const MsbWs &ws, uint32_t off, uint32_t size)
+{
+    const uint32_t tl = 1u << ws.tile_shift, r = off & (MSB_TILE_ALIGN - 1u);
+    if (r == 0u || size < MSB_ALIGN_MIN_TILES * tl) return size < tl ? size : tl;
+    return tl - r;
+}
+__host__ __device__ inline uint32_t ws_tiles_of_at(const MsbWs &ws, uint32_t off, uint32_t size)   // size >= 1
+{
+    return 1u + ws_tiles_of(ws, size - ws_first_tile(ws, off, size));
+}
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // `extra`: pieces of the multi-GPU finish (each may add a ragged tile), 0 otherwise
 static inline uint32_t msb_max_buckets(uint64_t n, bool has_values, uint32_t extra = 0, uint32_t cap_max = 0)
@@ -158,10 +175,11 @@ static inline uint32_t msb_max_tasks(uint64_t n, bool has_values, uint32_t extra
     // (+ two stranger ranges per heavy-hitter bucket)
     return (uint32_t)(2 * n / MSB_MERGE) + 3 * msb_max_buckets(n, has_values, extra, cap_max) + 2 * RADIX + extra_tasks;
 }
-// tiles of a level: n / TILE full ones + one ragged tile per bucket, padded to whole chunks + one spare chunk
+// tiles of a level: n / TILE full ones + one ragged tile per bucket (+ a second one for the buckets of MSB_ALIGN_MIN_TILES tiles or
+// more, see ws_first_tile), padded to whole chunks + one spare chunk
 static inline uint32_t msb_max_tiles(uint64_t n, bool has_values, uint32_t extra = 0, uint32_t cap_max = 0, uint32_t tile = MSB_TILE)
 {
-    const uint64_t t = n / tile + msb_max_buckets(n, has_values, extra, cap_max) + 1;
+    const uint64_t t = n / tile + msb_max_buckets(n, has_values, extra, cap_max) + n / ((uint64_t)MSB_ALIGN_MIN_TILES * tile) + 2;
     return (uint32_t)((t / MSB_WAVES + 2) * MSB_WAVES);
 }
 // `wide_cap` != 0: the geometry of the wide kernels (tiles of 4096 elements, largest local sort of `wide_cap` elements)
@@ -249,11 +267,12 @@ __global__ __launch_bounds__(256) void msb_expand_kernel(MsbWs ws, int L, const 
             const uint32_t hits = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(lane < 16u && smp == cand));
             if (lane == 0) ws.pivots[b] = MsbPivot{cand, 0u, 0u, 0u, 0u, 0u, hits >= 3u ? 1u : 0u, 0u};
         }
+        const uint32_t tl = 1u << ws.tile_shift, v0 = ws_first_tile(ws, B.offset, B.size);
         for (uint32_t t = threadIdx.x; t < B.tiles; t += blockDim.x) {
-            const uint32_t tl = 1u << ws.tile_shift;
-            const uint32_t lo = B.offset + t * tl, left = B.size - t * tl;
+            const uint32_t before = t ? v0 + (t - 1u) * tl : 0u, left = B.size - before;       // (tile 0 may be the short one)
+            const uint32_t len = t ? (left < tl ? left : tl) : v0;
             if (B.tile_start + t < ws.max_tiles)
-                ws.tiles[B.tile_start + t] = MsbTile{lo, left < tl ? left : tl, b, 0u};
+                ws.tiles[B.tile_start + t] = MsbTile{B.offset + before, len, b, 0u};
             else MSB_OVERFLOW(ws);
         }
     }
@@ -603,7 +622,7 @@ __global__ __launch_bounds__(256) void msb_classify_kernel(MsbWs ws, int L, cons
         const uint32_t tsize = s_task[d];
         int cls = 0;
         if (tsize) while (ws.caps[cls] < tsize) ++cls;
-        const uint32_t tiles = is_large ? ws_tiles_of(ws, c) : 0u;
+        const uint32_t tiles = is_large ? ws_tiles_of_at(ws, abs, c) : 0u;
         // exclusive prefixes inside the block (bucket index, tile index) keep tile_start sorted
         const uint32_t bidx = block_exclusive_scan_256(is_large ? 1u : 0u, scratch, &s_tot[0]);
         const uint32_t tidx = block_exclusive_scan_256(tiles, scratch, &s_tot[1]);
@@ -998,42 +1017,60 @@ __global__ __launch_bounds__(MSB_THREADS, HAS_VALUES ? 4 : 6) void msb_scatter_k
 {
     __shared__ __attribute__((aligned(16))) ScatterSmem<HAS_VALUES, REMAP> sm;
     const unsigned long long packed = ws.level[L].packed;
-    uint32_t g;
+    // one tile: nothing to do if it is not this kernel's kind (FULL: full tiles, else: ragged ones) -- uniform for the workgroup
+    auto one_tile = [&](uint32_t g) {
+        const MsbTile T = ws.tiles[g];
+        if (FULL ? T.valid != (uint32_t)MSB_TILE : T.valid == (uint32_t)MSB_TILE) return;
+        if (PIVOT && ws.pivots[T.bucket].flag) {
+            const MsbBucket B = ws.buckets[L & 1][T.bucket];
+            const bool in_place = result_k == src_k;
+            if constexpr (HAS_VALUES) {
+                // (not in place: the level's destination IS the result buffer, level 1)
+                msb_pivot_tile_pairs<FULL>(sm.gbase, ws.pivots + T.bucket, B, src_k, src_v, dst_k, dst_v, in_place ? (uint32_t *)nullptr : result_k,
+                                           in_place ? dst_v : result_v, T.lo, T.valid, pivot_f32_out, pivot_xor_out);
+            } else {
+                msb_pivot_tile<FULL>(sm.gbase, ws.pivots + T.bucket, B, src_k, dst_k, result_k, T.lo, T.valid, pivot_f32_out, pivot_xor_out,
+                                     !in_place || pivot_f32_out != 0 || pivot_xor_out != 0u);
+            }
+            return;
+        }
+        if (REMAP) load_remap(ds, sm.tab);
+        msb_scatter_tile<HAS_VALUES, REMAP, TWOUT, FULL, BIG>(sm, ds, ws.cursors + (size_t)T.bucket * RADIX, ws.spine + g / MSB_WAVES,
+                                                              ws.stride, ws.prefix16 + (size_t)g * RADIX, src_k, dst_k, src_v, dst_v,
+                                                              T.lo, T.valid, f32_out, xor_out);
+    };
     if (FULL) {
         if (blockIdx.x >= (uint32_t)packed) return;
 #ifdef GS_MSB_WIDE_GROUP
-        g = tile_of_item_wide(blockIdx.x, (uint32_t)packed);
+        one_tile(tile_of_item_wide(blockIdx.x, (uint32_t)packed));
 #else
-        g = tile_of_item(blockIdx.x, (uint32_t)packed);   // neighbouring tiles on one XCD: their runs meet in one L2
+        one_tile(tile_of_item(blockIdx.x, (uint32_t)packed));   // neighbouring tiles on one XCD: their runs meet in one L2
 #endif
-    } else if (ragged_anywhere) {                         // buckets in pieces: one block per tile, full ones skipped
+    } else if (ragged_anywhere == 1) {                    // buckets in pieces: one block per tile, full ones skipped
         if (blockIdx.x >= (uint32_t)packed) return;
-        g = blockIdx.x;
+        one_tile(blockIdx.x);
     } else {
-        if (blockIdx.x >= (uint32_t)(packed >> 32)) return;
-        const MsbBucket B = ws.buckets[L & 1][blockIdx.x];
-        if (B.size % (uint32_t)MSB_TILE == 0) return;
-        g = B.tile_start + B.size / (uint32_t)MSB_TILE;
-    }
-    const MsbTile T = ws.tiles[g];
-    if (FULL ? T.valid != (uint32_t)MSB_TILE : T.valid == (uint32_t)MSB_TILE) return;
-    if (PIVOT && ws.pivots[T.bucket].flag) {
-        const MsbBucket B = ws.buckets[L & 1][T.bucket];
-        const bool in_place = result_k == src_k;
-        if constexpr (HAS_VALUES) {
-            // (not in place: the level's destination IS the result buffer, level 1)
-            msb_pivot_tile_pairs<FULL>(sm.gbase, ws.pivots + T.bucket, B, src_k, src_v, dst_k, dst_v, in_place ? (uint32_t *)nullptr : result_k,
-                                       in_place ? dst_v : result_v, T.lo, T.valid, pivot_f32_out, pivot_xor_out);
+        // one workgroup per bucket: its last tile and -- where the bucket's tiles were aligned (ws_first_tile) -- its first one may
+        // be ragged.  (Two workgroups per bucket, one per candidate: the launch of 12.5 K instead of 6.2 K workgroups, most of
+        // which leave at once, took 0.154 instead of 0.088 ms at level 2 of a 2^30-key Zipf sort.)
+        // With few buckets (level 1: 256) two workgroups per bucket after all (`ragged_anywhere` == 2): the two tiles of a bucket one
+        // after the other made the launch twice as long (17 -> 34 us).
+        const bool two = ragged_anywhere == 2;
+        const uint32_t b = two ? blockIdx.x >> 1 : blockIdx.x;
+        if (b >= (uint32_t)(packed >> 32)) return;
+        const MsbBucket B = ws.buckets[L & 1][b];
+        const bool short_first = B.tiles >= 2u && ws_first_tile(ws, B.offset, B.size) != (1u << ws.tile_shift);
+        if (two) {
+            if (blockIdx.x & 1u) { if (short_first) one_tile(B.tile_start); }
+            else one_tile(B.tile_start + B.tiles - 1u);
         } else {
-            msb_pivot_tile<FULL>(sm.gbase, ws.pivots + T.bucket, B, src_k, dst_k, result_k, T.lo, T.valid, pivot_f32_out, pivot_xor_out,
-                                 !in_place || pivot_f32_out != 0 || pivot_xor_out != 0u);
+            one_tile(B.tile_start + B.tiles - 1u);
+            if (short_first) {
+                __syncthreads();
+                one_tile(B.tile_start);
+            }
         }
-        return;
     }
-    if (REMAP) load_remap(ds, sm.tab);
-    msb_scatter_tile<HAS_VALUES, REMAP, TWOUT, FULL, BIG>(sm, ds, ws.cursors + (size_t)T.bucket * RADIX, ws.spine + g / MSB_WAVES,
-                                                          ws.stride, ws.prefix16 + (size_t)g * RADIX, src_k, dst_k, src_v, dst_v,
-                                                          T.lo, T.valid, f32_out, xor_out);
 }
 
 template <bool HAS_VALUES, bool REMAP, bool TWOUT>
@@ -1043,8 +1080,9 @@ static void launch_scatter(const MsbWs &ws, int L, uint32_t tiles_ub, uint32_t b
                            uint32_t pivot_xor_out = 0u, uint32_t *pivot_result_v = nullptr)
 {
     const dim3 blk(MSB_THREADS);
-    const dim3 rg(ragged_anywhere ? tiles_ub : buckets_ub);
-    const int ra = ragged_anywhere ? 1 : 0;
+    const bool two_per_bucket = !ragged_anywhere && buckets_ub <= 1024u;      // see msb_scatter_kernel
+    const dim3 rg(ragged_anywhere ? tiles_ub : two_per_bucket ? 2u * buckets_ub : buckets_ub);
+    const int ra = ragged_anywhere ? 1 : two_per_bucket ? 2 : 0;
     if constexpr (!REMAP) {
         if (pivot_result) {   // heavy-hitter buckets may exist at this level
             if (big) {
@@ -2045,7 +2083,7 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
         const bool pivot = allow_pivot && msb_pivot_enabled() && !in_pieces && L <= 2;
         // buckets at level L: <= 256 at level 1, else bounded by size; tiles: n/T + one ragged tile per bucket (piece)
         uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
-        uint32_t max_tiles = tiles_all + (in_pieces ? npieces : max_b);
+        uint32_t max_tiles = tiles_all + (in_pieces ? npieces : max_b + tiles_all / MSB_ALIGN_MIN_TILES + 1u);
         if (known && L >= 2) {                 // exact (never more than the bounds above)
             if (known_b < max_b) max_b = known_b;
             if (known_tiles < max_tiles) max_tiles = known_tiles;
@@ -2181,7 +2219,7 @@ __global__ __launch_bounds__(256) void seg_classify_kernel(MsbWs ws, const int *
             if (sz != 0 && tiny_cap != 0 && sz <= 4u * tiny_cap) list[j] = sz <= (uint32_t)WAVE ? 3 : sz <= tiny_cap ? 0 : sz <= 2u * tiny_cap ? 1 : 2;
             else if (sz != 0 && sz <= cap_max) { int c = 0; while (ws.caps[c] < sz) ++c; list[j] = NW + c; }
             else if (sz > cap_max) {          // a bucket of the level (rare: one atomic each)
-                const uint32_t tiles = ws_tiles_of(ws, sz);
+                const uint32_t tiles = ws_tiles_of_at(ws, b[j], sz);
                 const unsigned long long old = atomicAdd(&ws.level[1].packed, (1ull << 32) | tiles);
                 if ((uint32_t)(old >> 32) < ws.max_buckets) ws.buckets[1][(uint32_t)(old >> 32)] = MsbBucket{b[j], sz, (uint32_t)old, tiles};
                 else MSB_OVERFLOW(ws);
@@ -2842,7 +2880,7 @@ static int msb_wide_sort(void *d_temp, K *keys, V *vals, uint64_t num_items, K *
         V *dv = buf_v[(L + 1) & 1];
         const bool last = L == KB - 1;
         uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
-        uint32_t max_tiles = tiles_all + max_b;
+        uint32_t max_tiles = tiles_all + max_b + tiles_all / MSB_ALIGN_MIN_TILES + 1u;
         if (known && L >= 2) {
             if (known_b < max_b) max_b = known_b;
             if (known_tiles < max_tiles) max_tiles = known_tiles;

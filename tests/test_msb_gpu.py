@@ -405,3 +405,22 @@ def test_heavy_hitter_path_pairs(gs, cuda, oracle, share, level):
             cen = msb_census(dm, n, True)
             assert sum(c["pivot_keys"] for c in cen) >= int(share * n * 0.99)
             assert cen[level]["pivot_keys"] >= int(share * n * 0.99)
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+def test_large_buckets_at_odd_offsets(gs, cuda, oracle, pairs):
+    """Buckets of 256 tiles or more whose offset is no multiple of 64 elements get a short first tile so that their other tiles start
+    on 256-byte boundaries (ws_first_tile, gs_msb.hip): three top bytes with 3 000 001 / 2 500 003 / 2 600 005 keys, so that the second
+    and third level-1 bucket start at odd offsets and carry two ragged tiles each."""
+    rng = np.random.default_rng(12)
+    sizes = [3_000_001, 2_500_003, 2_600_005]
+    tops = [0x11, 0x5A, 0xC3]
+    keys = np.concatenate([(np.uint32(t) << np.uint32(24)) | (rng.integers(0, 1 << 24, m, dtype=np.uint32)) for t, m in zip(tops, sizes)])
+    rng.shuffle(keys)
+    n = keys.size
+    if not pairs:
+        assert np.array_equal(_msb_keys(gs, keys, cuda), np.sort(keys))
+    else:
+        vals = oracle.gen_enumerated(n)
+        ks, vs = _msb_pairs(gs, keys, vals, cuda)
+        assert oracle.msb_check_pairs_enumerated(keys, ks, vs) == 0
