@@ -150,12 +150,22 @@ __host__ __device__ inline uint32_t ws_tiles_of(const MsbWs &ws, uint32_t x)
 // 2^30 keys took 0.75 ms instead of 0.84 and the scatter 1.71 instead of 1.78 (tools/align_exp.py).  Small buckets keep one ragged
 // tile (their last): a second one would cost them more than the alignment gives.
 constexpr uint32_t MSB_TILE_ALIGN = 64, MSB_ALIGN_MIN_TILES = 256;
-__host__ __device__ inline uint32_t ws_first_tile(const MsbWs &ws, uint32_t off, uint32_t size)
+__host__ __device__ inline uint32_t ws_first_tile(const MsbWs &ws, uint32_t off, uint32_t size, uint32_t min_tiles = MSB_ALIGN_MIN_TILES)
 {
     const uint32_t tl = 1u << ws.tile_shift, r = off & (MSB_TILE_ALIGN - 1u);
-    if (r == 0u || size < MSB_ALIGN_MIN_TILES * tl) return size < tl ? size : tl;
+    if (r == 0u || size < min_tiles * tl) return size < tl ? size : tl;
     return tl - r;
 }
+// the pieces a bucket arrives in (multi-GPU finish): every tile of that level may be ragged anyway (one workgroup per tile in the
+// ragged launch), so pieces of 16 tiles or more are aligned
+constexpr uint32_t MSB_PIECE_ALIGN_MIN_TILES = 16;
+__host__ __device__ inline uint32_t msb_piece_first_tile(uint32_t off, uint32_t size)
+{
+    const uint32_t tl = (uint32_t)MSB_TILE, r = off & (MSB_TILE_ALIGN - 1u);
+    if (r == 0u || size < MSB_PIECE_ALIGN_MIN_TILES * tl) return size < tl ? size : tl;
+    return tl - r;
+}
+__host__ __device__ inline uint32_t msb_piece_tiles(uint32_t off, uint32_t size) { return 1u + msb_tiles_of(size - msb_piece_first_tile(off, size)); }
 __host__ __device__ inline uint32_t ws_tiles_of_at(const MsbWs &ws, uint32_t off, uint32_t size)   // size >= 1
 {
     return 1u + ws_tiles_of(ws, size - ws_first_tile(ws, off, size));
@@ -284,11 +294,12 @@ __global__ __launch_bounds__(256) void msb_expand_pieces_kernel(MsbWs ws, uint32
 {
     for (uint32_t q = blockIdx.x; q < npieces; q += gridDim.x) {
         const MsbPiece P = ws.pieces[q];
-        const uint32_t tiles = msb_tiles_of(P.size);
+        const uint32_t tiles = msb_piece_tiles(P.lo, P.size), v0 = msb_piece_first_tile(P.lo, P.size);
         for (uint32_t t = threadIdx.x; t < tiles; t += blockDim.x) {
-            const uint32_t left = P.size - t * MSB_TILE;
+            const uint32_t before = t ? v0 + (t - 1u) * (uint32_t)MSB_TILE : 0u, left = P.size - before;
+            const uint32_t len = t ? (left < (uint32_t)MSB_TILE ? left : (uint32_t)MSB_TILE) : v0;
             if (P.tile_start + t < ws.max_tiles)
-                ws.tiles[P.tile_start + t] = MsbTile{P.lo + t * MSB_TILE, left < (uint32_t)MSB_TILE ? left : (uint32_t)MSB_TILE, P.bucket, 0u};
+                ws.tiles[P.tile_start + t] = MsbTile{P.lo + before, len, P.bucket, 0u};
             else MSB_OVERFLOW(ws);
         }
     }
@@ -2083,7 +2094,7 @@ static void msb_run_levels(const MsbWs &ws, uint64_t num_items, bool pairs, uint
         const bool pivot = allow_pivot && msb_pivot_enabled() && !in_pieces && L <= 2;
         // buckets at level L: <= 256 at level 1, else bounded by size; tiles: n/T + one ragged tile per bucket (piece)
         uint32_t max_b = (L == 1) ? (uint32_t)RADIX : ws.max_buckets;
-        uint32_t max_tiles = tiles_all + (in_pieces ? npieces : max_b + tiles_all / MSB_ALIGN_MIN_TILES + 1u);
+        uint32_t max_tiles = tiles_all + (in_pieces ? 2u * npieces : max_b + tiles_all / MSB_ALIGN_MIN_TILES + 1u);
         if (known && L >= 2) {                 // exact (never more than the bounds above)
             if (known_b < max_b) max_b = known_b;
             if (known_tiles < max_tiles) max_tiles = known_tiles;
@@ -3255,7 +3266,7 @@ int gs_msb_finish_u32(void *d_temp, size_t temp_bytes, uint32_t *d_keys, uint32_
                 const uint64_t c = h_piece_counts[sidx * RADIX + b];
                 if (c == 0) continue;
                 ht->hp[np++] = MsbPiece{(uint32_t)src_off[sidx * RADIX + b], (uint32_t)c, tile, nb};
-                tile += (uint32_t)((c + MSB_TILE - 1) / MSB_TILE);
+                tile += msb_piece_tiles((uint32_t)src_off[sidx * RADIX + b], (uint32_t)c);
             }
             ht->hb[nb++] = MsbBucket{(uint32_t)out_off, (uint32_t)size, tile_start, tile - tile_start};
             out_off += size;
