@@ -149,7 +149,10 @@ __host__ __device__ inline uint32_t ws_tiles_of(const MsbWs &ws, uint32_t x)
 // three.  With every bucket's top byte holding exactly n/256 keys (all tiles aligned like the LSB sort's) the level-1 histogram of
 // 2^30 keys took 0.75 ms instead of 0.84 and the scatter 1.71 instead of 1.78 (tools/align_exp.py).  Small buckets keep one ragged
 // tile (their last): a second one would cost them more than the alignment gives.
-constexpr uint32_t MSB_TILE_ALIGN = 64, MSB_ALIGN_MIN_TILES = 256;
+#ifndef GS_MSB_ALIGN_MIN_TILES
+#define GS_MSB_ALIGN_MIN_TILES 256
+#endif
+constexpr uint32_t MSB_TILE_ALIGN = 64, MSB_ALIGN_MIN_TILES = GS_MSB_ALIGN_MIN_TILES;
 __host__ __device__ inline uint32_t ws_first_tile(const MsbWs &ws, uint32_t off, uint32_t size, uint32_t min_tiles = MSB_ALIGN_MIN_TILES)
 {
     const uint32_t tl = 1u << ws.tile_shift, r = off & (MSB_TILE_ALIGN - 1u);
