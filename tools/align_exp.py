@@ -15,7 +15,12 @@ al = torch.where(al >= 2**31, al - 2**32, al).to(torch.int32)
 del idx
 work, alt = torch.empty_like(uni), torch.empty_like(uni)
 dm = torch.empty(gs.lib.gs_msb_temp_bytes(n, 0), dtype=torch.uint8, device=dev)
-for name, src in (("uniform", uni), ("aligned buckets", al), ("uniform", uni), ("aligned buckets", al)):
+# exactly n/65536 keys per 16-bit prefix: every local-sort task of level 1 starts on a multiple of 16384 keys
+idx = torch.arange(n, device=dev, dtype=torch.int64)
+al2 = (((idx & 65535) << 16) | (uni.to(torch.int64) & 0xFFFF))
+al2 = torch.where(al2 >= 2**31, al2 - 2**32, al2).to(torch.int32)
+del idx
+for name, src in (("uniform", uni), ("aligned buckets", al), ("aligned tasks", al2), ("uniform", uni), ("aligned buckets", al), ("aligned tasks", al2)):
     tot = {}
     for r in range(4):
         work.copy_(src)
