@@ -1815,10 +1815,18 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
         // ---- request the next task's keys, then store this one from the buffer
         if (has_next) request(Tn);
         LSP(13);                                          // request the next task's keys
+        // Aligned stores (round 3): a task's output starts wherever the sub-bucket before it ends, so a wave's 256-byte streaming stores
+        // straddled three cache lines, two of them partly.  Where the class has room (size + shift <= capacity) thread t stores the
+        // elements t - shift, t - shift + THREADS, ... (shift = offset mod 64 elements): every wave's store starts on a 256-byte
+        // boundary.  The buffer's slots are still read (and cleared) exactly once each: the slots in front of element 0 wrap to its end.
+        constexpr uint32_t CAP = (uint32_t)(KPT * THREADS);
+        const uint32_t ssh = (T.size + (T.offset & 63u) <= CAP) ? (T.offset & 63u) : 0u;
         if (done) {
         uint32_t *qk = dst_k + T.offset, *qv = HAS_VALUES ? dst_v + T.offset : nullptr;
         if (HAS_VALUES) {
-            for (uint32_t j = tid; j < T.size; j += THREADS) {
+            for (uint32_t jj = tid; jj < T.size + ssh; jj += THREADS) {
+                const uint32_t j = jj - ssh;
+                if (j >= T.size) continue;
                 const uint2 kv = reinterpret_cast<const uint2 *>(sm.stage)[j];
                 // whole lines of final output, written once: streaming stores (+0.3...0.7 % on the whole sort)
                 __builtin_nontemporal_store(PLAIN ? kv.x : twiddle_out(kv.x, f32_out, xor_out), &qk[j]);
@@ -1826,17 +1834,22 @@ __global__ __launch_bounds__(THREADS, (THREADS == 1024 && !(HAS_VALUES && KPT > 
             }
         } else {
             const uint32_t t0 = fresh((uint32_t)tid);
+            // element t0 - shift + i * THREADS sits in the slot of the same number; only round 0 can lie in front of element 0
+            // (THREADS > shift), and its slot is then the one CAP further on: one base register, the rest immediate offsets
+            const uint32_t jb = t0 - ssh, s0 = jb < CAP ? jb : jb + CAP;
+            pos[0] = sm.stage[s0];
 #pragma unroll
-            for (int i = 0; i < KPT; ++i) pos[i] = sm.stage[t0 + i * THREADS];   // `pos` is free: batch the reads
+            for (int i = 1; i < KPT; ++i) pos[i] = sm.stage[jb + i * THREADS];   // `pos` is free: batch the reads
             if constexpr ((MODE == LS_ONEPASS || ls_is_dedupe(MODE)) && !HAS_VALUES) {
                 // the slots become the next task's byte counters (map and counters): each thread clears what it has just read
 #pragma unroll
-                for (int i = 0; i < KPT; ++i) sm.stage[t0 + i * THREADS] = 0;
+                for (int i = 1; i < KPT; ++i) sm.stage[jb + i * THREADS] = 0;
+                sm.stage[s0] = 0;
                 zeroed = true;
             }
 #pragma unroll
             for (int i = 0; i < KPT; ++i) {
-                const uint32_t j = t0 + i * THREADS;
+                const uint32_t j = jb + i * THREADS;
                 if (j < T.size) __builtin_nontemporal_store(PLAIN ? pos[i] : twiddle_out(pos[i], f32_out, xor_out), reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(qk) + j * 4u));
             }
         }
