@@ -2716,7 +2716,7 @@ __global__ __launch_bounds__(MW_THREADS, KPT > 8 ? 2 : 4) void mw_local_sort_ker
                     uint32_t run = inc - sum;
 #pragma unroll
                     for (int j = 0; j < MW_WAVES; ++j) run += j < w ? mw_wtot[j] : 0u;
-                    const uint32_t b0 = run, b1 = b0 + c4.x, b2 = b1 + c4.y, b3 = b2 + c4.z, b4 = b3 + c4.w;
+                    const uint32_t b0 = run, b1 = b0 + c4.x, b2 = b1 + c4.y, b3 = b2 + c4.z;
                     reinterpret_cast<uint4 *>(hist)[tid] = make_uint4(b0, b1, b2, b3);
                     __syncthreads();
                     // into the buffer, bin by bin; with values an element is {low 48 key bits : 48, its index : 16}, so elements are
