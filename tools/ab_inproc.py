@@ -24,9 +24,30 @@ for r in range(int(os.environ.get("CHURN", "0"))):
     del tmp
     torch.cuda.empty_cache()
 src = (gs.generate_zipf_keys if mode == "msbzipf" else gs.generate_uniform_keys)(n, device=dev)
-a, b = torch.empty_like(src), torch.empty_like(src)
-va = gs.generate_enumerated_values(n, device=dev) if pairs else None
-vb = torch.empty_like(src) if pairs else None
+if os.environ.get("SLAB"):
+    # the four arrays carved from ONE allocation (the reliably slow placement of the pairs sort, profiles/README.md round 3)
+    mode = os.environ["SLAB"]
+    pad = int(os.environ.get("SLAB_PAD", "0")) // 4            # elements between the carved arrays
+    if mode in ("1", "2"):
+        slab = torch.empty(4 * (n + pad), dtype=torch.int32, device=dev)
+        parts = [slab[i * (n + pad): i * (n + pad) + n] for i in range(4)]
+        a, va, b, vb = parts if mode == "1" else (parts[0], parts[2], parts[1], parts[3])    # 2: a, b, va, vb
+    elif mode == "3":                                           # inputs in one slab, outputs in another
+        s1, s2 = torch.empty(2 * (n + pad), dtype=torch.int32, device=dev), torch.empty(2 * (n + pad), dtype=torch.int32, device=dev)
+        a, va, b, vb = s1[0:n], s1[n + pad: 2 * n + pad], s2[0:n], s2[n + pad: 2 * n + pad]
+    elif mode == "4":                                           # keys in one slab, values in another
+        s1, s2 = torch.empty(2 * (n + pad), dtype=torch.int32, device=dev), torch.empty(2 * (n + pad), dtype=torch.int32, device=dev)
+        a, b, va, vb = s1[0:n], s1[n + pad: 2 * n + pad], s2[0:n], s2[n + pad: 2 * n + pad]
+    else:                                                       # 5: a and va in one slab, b and vb separate allocations
+        s1 = torch.empty(2 * (n + pad), dtype=torch.int32, device=dev)
+        a, va = s1[0:n], s1[n + pad: 2 * n + pad]
+        b, vb = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
+    if pairs: gs.generate_enumerated_values(n, device=dev, out=va)
+    else: va = vb = None
+else:
+    a, b = torch.empty_like(src), torch.empty_like(src)
+    va = gs.generate_enumerated_values(n, device=dev) if pairs else None
+    vb = torch.empty_like(src) if pairs else None
 nb = max(gs.lib.gs_lsb_temp_bytes(n, int(pairs)), gs.lib.gs_msb_temp_bytes(n, 0))
 temp = torch.empty(nb, dtype=torch.uint8, device=dev)
 libs = []
