@@ -28,7 +28,10 @@ if os.environ.get("SLAB"):
     # the four arrays carved from ONE allocation (the reliably slow placement of the pairs sort, profiles/README.md round 3)
     mode = os.environ["SLAB"]
     pad = int(os.environ.get("SLAB_PAD", "0")) // 4            # elements between the carved arrays
-    if mode in ("1", "2"):
+    if not pairs:                                               # keys only: a and b carved from one allocation
+        slab = torch.empty(2 * (n + pad), dtype=torch.int32, device=dev)
+        a, b = slab[0:n], slab[n + pad: 2 * n + pad]
+    elif mode in ("1", "2"):
         slab = torch.empty(4 * (n + pad), dtype=torch.int32, device=dev)
         parts = [slab[i * (n + pad): i * (n + pad) + n] for i in range(4)]
         a, va, b, vb = parts if mode == "1" else (parts[0], parts[2], parts[1], parts[3])    # 2: a, b, va, vb
